@@ -1,0 +1,326 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY -- see af_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+import subprocess
+
+import numpy as np
+
+HERE = pathlib.Path(__file__).resolve().parent
+LIB_PATH = HERE / "libaf_oracle.so"
+
+
+def build(force: bool = False) -> pathlib.Path:
+    src_newer = (not LIB_PATH.exists()) or any(
+        (HERE / f).stat().st_mtime > LIB_PATH.stat().st_mtime
+        for f in ("af_oracle.c", "af_oracle.h", "tp_fir_table.h", "af_rnnoise.c")
+        if (HERE / f).exists()
+    )
+    if force or src_newer:
+        subprocess.run(["make", "-C", str(HERE), "-s"], check=True)
+    return LIB_PATH
+
+
+class EqBandConfig(C.Structure):
+    _fields_ = [
+        ("filter_type", C.c_int32),
+        ("frequency_hz", C.c_double),
+        ("gain_db", C.c_double),
+        ("q", C.c_double),
+        ("slope_db_per_octave", C.c_int32),
+        ("enabled", C.c_int32),
+    ]
+
+
+EQ_TYPE_IDS = {"low_shelf": 0, "bell": 1, "high_shelf": 2, "notch": 3, "high_pass": 4, "low_pass": 5}
+
+
+class SimSettings(C.Structure):
+    _fields_ = [
+        ("has_eq_bands_v2", C.c_int32),
+        ("eq_bands_v2", EqBandConfig * 10),
+        ("deesser_enabled", C.c_int32),
+        ("deesser_auto_enabled", C.c_int32),
+        ("deesser_auto_amount", C.c_double),
+        ("deesser_low_cut_hz", C.c_double),
+        ("deesser_high_cut_hz", C.c_double),
+        ("deesser_threshold_db", C.c_double),
+        ("deesser_ratio", C.c_double),
+        ("deesser_attack_ms", C.c_double),
+        ("deesser_release_ms", C.c_double),
+        ("deesser_max_reduction_db", C.c_double),
+        ("eq_before_deesser", C.c_int32),
+        ("compressor_enabled", C.c_int32),
+        ("compressor_threshold_db", C.c_double),
+        ("compressor_ratio", C.c_double),
+        ("compressor_attack_ms", C.c_double),
+        ("compressor_release_ms", C.c_double),
+        ("compressor_makeup_gain_db", C.c_double),
+        ("compressor_adaptive_release", C.c_int32),
+        ("compressor_base_release_ms", C.c_double),
+        ("compressor_auto_makeup_enabled", C.c_int32),
+        ("compressor_target_lufs", C.c_double),
+        ("compressor_sidechain_highpass_enabled", C.c_int32),
+        ("limiter_enabled", C.c_int32),
+        ("limiter_ceiling_db", C.c_double),
+        ("limiter_careful_output_enabled", C.c_int32),
+        ("limiter_lookahead_ms", C.c_double),
+        ("limiter_release_ms", C.c_double),
+    ]
+
+
+class SimResult(C.Structure):
+    _fields_ = [
+        ("input_sample_peak_db", C.c_float),
+        ("input_rms_db", C.c_float),
+        ("output_sample_peak_db", C.c_float),
+        ("pre_limiter_true_peak_db", C.c_float),
+        ("output_true_peak_db", C.c_float),
+        ("output_rms_db", C.c_float),
+        ("limiter_effective_ceiling_db", C.c_float),
+        ("sample_headroom_db", C.c_float),
+        ("pre_limiter_true_peak_headroom_db", C.c_float),
+        ("true_peak_headroom_db", C.c_float),
+        ("limiter_gain_reduction_db", C.c_float),
+        ("true_peak_limiter_gain_reduction_db", C.c_float),
+        ("true_peak_limited_events", C.c_uint64),
+        ("compressor_gain_reduction_db", C.c_float),
+        ("deesser_gain_reduction_db", C.c_float),
+        ("compressor_gain_reduction_median_db", C.c_float),
+        ("compressor_gain_reduction_p95_db", C.c_float),
+        ("compressor_gain_reduction_active_ratio", C.c_float),
+        ("active_output_gain_db", C.c_float),
+        ("silence_output_gain_db", C.c_float),
+        ("silence_level_delta_db", C.c_float),
+        ("compressor_pumping_score_db", C.c_float),
+        ("non_finite_output", C.c_int32),
+        ("deesser_gain_reduction_median_db", C.c_float),
+        ("deesser_gain_reduction_p95_db", C.c_float),
+        ("analysis_block_ms", C.c_float),
+        ("active_analysis_threshold_db", C.c_float),
+        ("active_analysis_block_count", C.c_uint64),
+        ("processed_samples", C.c_uint64),
+    ]
+
+
+class EqV2Result(C.Structure):
+    _fields_ = [
+        ("input_sample_peak", C.c_float),
+        ("output_sample_peak", C.c_float),
+        ("input_true_peak", C.c_float),
+        ("output_true_peak", C.c_float),
+        ("input_rms", C.c_double),
+        ("output_rms", C.c_double),
+        ("max_response_db", C.c_double),
+        ("sample_count", C.c_uint64),
+        ("non_finite_output", C.c_int32),
+    ]
+
+
+class BlockStats(C.Structure):
+    _fields_ = [
+        ("input_sample_peak", C.c_float),
+        ("output_sample_peak", C.c_float),
+        ("true_peak_limiter_input_peak", C.c_float),
+        ("output_true_peak", C.c_float),
+        ("limiter_peak_gain_reduction_db", C.c_float),
+        ("true_peak_limiter_gain_reduction_db", C.c_float),
+        ("true_peak_limited_events", C.c_uint64),
+        ("compressor_gain_reduction_db", C.c_float),
+        ("deesser_gain_reduction_db", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(LIB_PATH))
+        vp, d, i, f, sz = C.c_void_p, C.c_double, C.c_int, C.c_float, C.c_size_t
+        fp = C.POINTER(C.c_float)
+        dp = C.POINTER(C.c_double)
+        L.afo_chain_new.restype = vp
+        L.afo_chain_new.argtypes = [d]
+        L.afo_chain_free.argtypes = [vp]
+        for name in ("deesser", "eq", "compressor", "limiter", "tp_limiter"):
+            fn = getattr(L, f"afo_chain_{name}")
+            fn.restype = vp
+            fn.argtypes = [vp]
+        for name in ("deesser_enabled", "eq_enabled", "compressor_enabled", "limiter_enabled", "eq_before_deesser"):
+            getattr(L, f"afo_chain_set_{name}").argtypes = [vp, i]
+        L.afo_chain_process_block.restype = BlockStats
+        L.afo_chain_process_block.argtypes = [vp, fp, sz]
+        for name in ("gain", "frequency", "q"):
+            getattr(L, f"afo_eq_set_band_{name}").argtypes = [vp, sz, d]
+        L.afo_eq_set_band_config.argtypes = [vp, sz, C.POINTER(EqBandConfig)]
+        L.afo_eq_reset.argtypes = [vp]
+        for name in ("threshold", "ratio", "attack_time", "release_time", "base_release_time", "makeup_gain",
+                     "target_lufs", "noise_reference_reliability", "limiter_feedback_gain_reduction_db"):
+            getattr(L, f"afo_compressor_set_{name}").argtypes = [vp, d]
+        for name in ("adaptive_release", "enabled", "auto_makeup_enabled", "sidechain_highpass_enabled"):
+            getattr(L, f"afo_compressor_set_{name}").argtypes = [vp, i]
+        for name in ("ceiling", "release_time", "lookahead_ms"):
+            getattr(L, f"afo_limiter_set_{name}").argtypes = [vp, d]
+        L.afo_limiter_set_enabled.argtypes = [vp, i]
+        L.afo_tp_limiter_set_release_ms.argtypes = [vp, f]
+        L.afo_tp_limiter_set_ceiling_linear.argtypes = [vp, f]
+        for name in ("auto_amount", "low_cut_hz", "high_cut_hz", "threshold_db", "ratio", "attack_ms", "release_ms",
+                     "max_reduction_db"):
+            getattr(L, f"afo_deesser_set_{name}").argtypes = [vp, d]
+        for name in ("enabled", "auto_enabled"):
+            getattr(L, f"afo_deesser_set_{name}").argtypes = [vp, i]
+        L.afo_sim_settings_default.argtypes = [C.POINTER(SimSettings)]
+        L.afo_simulate_auto_eq_chain.restype = i
+        L.afo_simulate_auto_eq_chain.argtypes = [fp, sz, d, dp, C.POINTER(SimSettings), C.POINTER(SimResult), fp]
+        L.afo_simulate_eq_v2.restype = i
+        L.afo_simulate_eq_v2.argtypes = [fp, sz, d, C.POINTER(EqBandConfig), C.POINTER(EqV2Result), fp]
+        L.afo_eq_magnitude_response.restype = i
+        L.afo_eq_magnitude_response.argtypes = [dp, sz, dp, d, dp]
+        L.afo_eq_magnitude_response_v2.restype = i
+        L.afo_eq_magnitude_response_v2.argtypes = [dp, sz, C.POINTER(EqBandConfig), d, dp]
+        L.afo_kat_signal.argtypes = [fp, sz, C.c_uint64, d, d]
+        L.afo_time_constant_to_coeff.restype = d
+        L.afo_time_constant_to_coeff.argtypes = [d, d]
+        L.afo_db_to_linear.restype = d
+        L.afo_db_to_linear.argtypes = [d]
+        L.afo_linear_to_db.restype = d
+        L.afo_linear_to_db.argtypes = [d, d]
+        L.afo_percentile_f32.restype = f
+        L.afo_percentile_f32.argtypes = [fp, sz, f]
+        L.afo_pumping_score.restype = f
+        L.afo_pumping_score.argtypes = [fp, sz, f]
+        _lib = L
+    return _lib
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def kat_signal(n_blocks: int, noise_state: int = 0x6A09E667F3BCC909, f0: float = 180.0, phrase_hz: float = 1.7) -> np.ndarray:
+    out = np.zeros(n_blocks * 480, dtype=np.float32)
+    lib().afo_kat_signal(_fptr(out), n_blocks, C.c_uint64(noise_state & (2**64 - 1)), f0, phrase_hz)
+    return out
+
+
+def bands_v2_array(bands) -> "C.Array":
+    arr = (EqBandConfig * 10)()
+    for k, (name, freq, gain, q, slope, enabled) in enumerate(bands):
+        if name not in EQ_TYPE_IDS:
+            raise ValueError(f"band {k} has unsupported EQ filter type: {name}")
+        arr[k] = EqBandConfig(EQ_TYPE_IDS[name], float(freq), float(gain), float(q), int(slope), int(bool(enabled)))
+    return arr
+
+
+def settings_from_dict(settings: dict | None) -> SimSettings:
+    s = SimSettings()
+    lib().afo_sim_settings_default(C.byref(s))
+    for key, value in (settings or {}).items():
+        if key == "eq_bands_v2":
+            s.has_eq_bands_v2 = 1
+            arr = bands_v2_array(value)
+            for k in range(10):
+                s.eq_bands_v2[k] = arr[k]
+        elif key == "return_output_audio":
+            continue
+        elif hasattr(s, key):
+            setattr(s, key, value)
+        else:
+            raise KeyError(key)
+    return s
+
+
+def simulate_auto_eq_chain(audio: np.ndarray, sample_rate: float, bands, settings: dict | None = None) -> dict:
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    if len(bands) != 10:
+        raise ValueError(f"expected 10 EQ bands, got {len(bands)}")
+    b = np.ascontiguousarray(np.asarray(bands, dtype=np.float64).reshape(10, 3))
+    s = settings_from_dict(settings)
+    r = SimResult()
+    out = np.zeros_like(audio)
+    rc = lib().afo_simulate_auto_eq_chain(_fptr(audio), audio.size, float(sample_rate), _dptr(b), C.byref(s), C.byref(r), _fptr(out))
+    if rc != 0:
+        raise ValueError("sample_rate must be positive and finite")
+    d = {name: getattr(r, name) for name, _ in SimResult._fields_}
+    d["non_finite_output"] = bool(d["non_finite_output"])
+    if (settings or {}).get("return_output_audio", False):
+        d["output_audio"] = out
+    return d
+
+
+def simulate_eq_v2(audio: np.ndarray, sample_rate: float, bands, return_output_audio: bool = False) -> dict:
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    if len(bands) != 10:
+        raise ValueError(f"expected 10 EQ bands, got {len(bands)}")
+    arr = bands_v2_array(bands)
+    r = EqV2Result()
+    out = np.zeros_like(audio)
+    rc = lib().afo_simulate_eq_v2(_fptr(audio), audio.size, float(sample_rate), arr, C.byref(r), _fptr(out))
+    if rc == -3:
+        raise ValueError("audio must contain only finite samples")
+    if rc != 0:
+        raise ValueError("invalid EQ configuration or sample_rate")
+    d = {name: getattr(r, name) for name, _ in EqV2Result._fields_}
+    d["non_finite_output"] = bool(d["non_finite_output"])
+    d["algorithmic_latency_samples"] = 0
+    if return_output_audio:
+        d["output_audio"] = out
+    return d
+
+
+def eq_magnitude_response(freqs, bands, sample_rate: float) -> np.ndarray:
+    f = np.ascontiguousarray(freqs, dtype=np.float64)
+    if len(bands) != 10:
+        raise ValueError(f"expected 10 EQ bands, got {len(bands)}")
+    b = np.ascontiguousarray(np.asarray(bands, dtype=np.float64).reshape(10, 3))
+    out = np.zeros_like(f)
+    rc = lib().afo_eq_magnitude_response(_dptr(f), f.size, _dptr(b), float(sample_rate), _dptr(out))
+    if rc != 0:
+        raise ValueError({-1: "sample_rate must be finite and positive", -2: "band frequency must be between 0 Hz and Nyquist", -3: "response frequencies must be finite and between 0 Hz and Nyquist"}[rc])
+    return out
+
+
+def eq_magnitude_response_v2(freqs, bands, sample_rate: float) -> np.ndarray:
+    f = np.ascontiguousarray(freqs, dtype=np.float64)
+    arr = bands_v2_array(bands)
+    out = np.zeros_like(f)
+    rc = lib().afo_eq_magnitude_response_v2(_dptr(f), f.size, arr, float(sample_rate), _dptr(out))
+    if rc != 0:
+        raise ValueError("invalid EQ v2 request")
+    return out
+
+
+class Chain:
+    """Thin handle on afo_chain (OfflineDspBlockProcessor restatement)."""
+
+    def __init__(self, sample_rate: float = 48000.0):
+        self.L = lib()
+        self.h = self.L.afo_chain_new(float(sample_rate))
+        self.eq = self.L.afo_chain_eq(self.h)
+        self.compressor = self.L.afo_chain_compressor(self.h)
+        self.limiter = self.L.afo_chain_limiter(self.h)
+        self.tp_limiter = self.L.afo_chain_tp_limiter(self.h)
+        self.deesser = self.L.afo_chain_deesser(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.afo_chain_free(self.h)
+            self.h = None
+
+    def set(self, what: str, value) -> None:
+        getattr(self.L, f"afo_chain_set_{what}")(self.h, int(value))
+
+    def process_block(self, block: np.ndarray) -> BlockStats:
+        assert block.dtype == np.float32 and block.flags.c_contiguous
+        return self.L.afo_chain_process_block(self.h, _fptr(block), block.size)
