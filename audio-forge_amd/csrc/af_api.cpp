@@ -1,0 +1,519 @@
+// af_api.cpp -- the C ABI of include/audioforge_mi.h on top of the host mirror and the kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/audioforge_mi.h"
+#include "af_device.h"
+#include "af_host.hpp"
+
+namespace af {
+size_t lane_kernel_dynamic_lds(int lookahead_samples);
+hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipStream_t stream);
+}  // namespace af
+
+static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
+static_assert(sizeof(af_block_stats) == 56, "stats row size");
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define AF_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t err__ = (expr);                                                                    \
+    if (err__ != hipSuccess)                                                                      \
+      return fail(AF_ERR_BACKEND, "%s failed: %s", #expr, hipGetErrorString(err__));              \
+  } while (0)
+
+}  // namespace
+
+struct af_engine {
+  af::ChainProto proto;
+  int n_streams;
+  int device;
+  bool started = false;
+  bool params_dirty = true;
+  int kernel = AF_KERNEL_AUTO;
+  bool timing = false;
+  int64_t samples_processed = 0;
+  int64_t last_blocks = 0;
+  double last_kernel_ms = 0.0;
+  int last_launches = 0;
+
+  af::ChainParams host_params{};
+  af::ChainParams *d_params = nullptr;
+  double *d_st64 = nullptr;
+  float *d_st32 = nullptr;
+  int n_f64 = 0, n_f32 = 0;
+  af::BlockStats *d_stats = nullptr;
+  int64_t stats_capacity = 0;  // rows
+  float *d_io = nullptr;       // staging for the host entry point
+  int64_t io_capacity = 0;     // floats
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+
+  af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}
+};
+
+namespace {
+
+int require_config(af_engine *e) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (e->started)
+    return fail(AF_ERR_STATE, "setter called after streaming started; call af_engine_reset first");
+  e->params_dirty = true;
+  return AF_OK;
+}
+
+int check_band(int32_t band) {
+  if (band < 0 || band >= af::kNumBands) return fail(AF_ERR_INVALID_ARGUMENT, "band index %d out of range", band);
+  return AF_OK;
+}
+
+af::EqBandConfig to_cfg(const af_eq_band_config &c) {
+  return af::EqBandConfig{c.filter_type, c.frequency_hz, c.gain_db, c.q, c.slope_db_per_octave, c.enabled != 0};
+}
+
+// Flatten the prototype into ChainParams (uniform) ...
+void export_params(af_engine *e) {
+  const af::ChainProto &p = e->proto;
+  af::ChainParams &o = e->host_params;
+  std::memset(&o, 0, sizeof o);
+  uint32_t f = 0;
+  if (p.deesser_enabled) f |= af::kFlagDeesser;
+  if (p.eq_enabled) f |= af::kFlagEq;
+  if (p.compressor_enabled) f |= af::kFlagCompressor;
+  if (p.limiter_enabled) f |= af::kFlagLimiter;
+  if (p.eq_before_deesser) f |= af::kFlagEqBeforeDeesser;
+  if (p.input_scrub) f |= af::kFlagInputScrub;
+  if (p.input_clamp) f |= af::kFlagInputClamp;
+  if (p.dc_block) f |= af::kFlagDcBlock;
+  if (p.pre_highpass) f |= af::kFlagPreHighpass;
+  o.flags = f;
+  o.control_block = p.control_block;
+  o.pre_hp = af::rbj_coefficients(af::BiquadType::HighPass, 80.0, 0.0, 0.707, p.sample_rate);
+  int n = 0;
+  for (int b = 0; b < af::kNumBands; ++b)
+    for (int s = 0; s < p.eq.bands[b].processing_sections; ++s) o.eq[n++] = p.eq.bands[b].sections[s].section();
+  o.n_eq_sections = n;
+  o.comp = p.compressor.params();
+  o.lim = p.limiter.params();
+  // block_processor.rs:150-151: the TP ceiling follows the limiter ceiling on every block
+  af::TruePeakProto tp = p.tp_limiter;
+  tp.set_ceiling_linear(std::pow(10.0f, (float)p.limiter.ceiling_db / 20.0f));
+  o.tp.ceiling_linear = tp.ceiling_linear;
+  o.tp.release_coeff = tp.release_coeff;
+}
+
+// ... and the initial per-stream state planes.
+int upload_initial_state(af_engine *e) {
+  const af::ChainProto &p = e->proto;
+  const int64_t B = e->n_streams;
+  const int nsec = e->host_params.n_eq_sections;
+  const int n64 = af::f64_field_count(nsec);
+  const int n32 = af::f32_field_count(p.limiter.lookahead_samples);
+  if (e->d_st64 && (n64 != e->n_f64 || n32 != e->n_f32)) {
+    AF_HIP(hipFree(e->d_st64));
+    AF_HIP(hipFree(e->d_st32));
+    e->d_st64 = nullptr;
+    e->d_st32 = nullptr;
+  }
+  if (!e->d_st64) {
+    AF_HIP(hipMalloc(&e->d_st64, sizeof(double) * n64 * B));
+    AF_HIP(hipMalloc(&e->d_st32, sizeof(float) * n32 * B));
+    e->n_f64 = n64;
+    e->n_f32 = n32;
+  }
+  std::vector<double> v64(n64, 0.0);
+  std::vector<float> v32(n32, 0.0f);
+  const af::CompressorProto &c = p.compressor;
+  v64[af::kCompPeakEnvDb] = -120.0;
+  v64[af::kCompGr] = c.current_gain_reduction_db;
+  v64[af::kCompFastEnv] = c.fast_release_env_db;
+  v64[af::kCompSlowEnv] = c.slow_release_env_db;
+  v64[af::kCompCurReleaseMs] = c.current_release_ms;
+  v64[af::kCompTargetReleaseMs] = c.target_release_ms;
+  // compressor.rs:760-761: release_coeff is tc(current_release_ms) from the first sample on
+  v64[af::kCompReleaseCoeff] = af::time_constant_to_coeff(c.current_release_ms, c.sample_rate);
+  v64[af::kCompSmoothedMakeup] = c.smoothed_makeup_gain;
+  v64[af::kCompCurrentLufs] = -100.0;
+  v64[af::kLimGain] = 1.0;
+  v32[af::kTpGain] = 1.0f;
+  // broadcast: every stream starts from the prototype
+  std::vector<double> plane64((size_t)n64 * B);
+  std::vector<float> plane32((size_t)n32 * B);
+  for (int f = 0; f < n64; ++f) std::fill_n(plane64.begin() + (size_t)f * B, B, v64[f]);
+  for (int f = 0; f < n32; ++f) std::fill_n(plane32.begin() + (size_t)f * B, B, v32[f]);
+  AF_HIP(hipMemcpy(e->d_st64, plane64.data(), plane64.size() * sizeof(double), hipMemcpyHostToDevice));
+  AF_HIP(hipMemcpy(e->d_st32, plane32.data(), plane32.size() * sizeof(float), hipMemcpyHostToDevice));
+  return AF_OK;
+}
+
+int ensure_started(af_engine *e) {
+  AF_HIP(hipSetDevice(e->device));
+  if (!e->started) {
+    if (e->proto.deesser_enabled) return fail(AF_ERR_UNSUPPORTED, "the de-esser stage is not built for the GPU yet");
+    if (e->proto.compressor.auto_makeup_enabled)
+      return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is not built for the GPU yet");
+    if (e->proto.limiter_enabled && e->proto.limiter.lookahead_samples > af::kLdsLookaheadMax)
+      return fail(AF_ERR_UNSUPPORTED, "limiter lookahead of %d samples exceeds the LDS-resident ring (%d)",
+                  e->proto.limiter.lookahead_samples, af::kLdsLookaheadMax);
+    export_params(e);
+    if (!e->d_params) AF_HIP(hipMalloc(&e->d_params, sizeof(af::ChainParams)));
+    int rc = upload_initial_state(e);
+    if (rc) return rc;
+    e->params_dirty = true;
+    e->started = true;
+    e->samples_processed = 0;
+  }
+  return AF_OK;
+}
+
+// after a launch of n samples: advance the (stream-uniform) crossfade counters
+void advance_crossfades(af_engine *e, int64_t n) {
+  af::ChainParams &o = e->host_params;
+  for (int k = 0; k < o.n_eq_sections; ++k) {
+    af::SectionParams &sp = o.eq[k];
+    if (sp.xf_remaining > 0) {
+      if (n >= sp.xf_remaining) {  // promote_pending_coefficients, biquad.rs:276-286
+        sp.active = sp.pending;
+        sp.xf_remaining = 0;
+        sp.xf_total = 0;
+      } else {
+        sp.xf_remaining -= (int)n;
+      }
+      e->params_dirty = true;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int af_version(void) { return 100; }
+const char *af_last_error(void) { return g_last_error.c_str(); }
+
+int af_device_count(void) {
+  int n = 0;
+  hipError_t err = hipGetDeviceCount(&n);
+  if (err != hipSuccess) return fail(AF_ERR_BACKEND, "hipGetDeviceCount failed: %s", hipGetErrorString(err));
+  return n;
+}
+
+int af_engine_create(double sample_rate, int32_t n_streams, int32_t device, af_engine **out) {
+  if (!out) return fail(AF_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (!std::isfinite(sample_rate) || sample_rate <= 0.0)
+    return fail(AF_ERR_INVALID_ARGUMENT, "sample_rate must be positive and finite");
+  if (n_streams <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_streams must be positive");
+  if (device < 0) return fail(AF_ERR_INVALID_ARGUMENT, "device must be >= 0");
+  *out = new af_engine(sample_rate, n_streams, device);
+  return AF_OK;
+}
+
+void af_engine_destroy(af_engine *e) {
+  if (!e) return;
+  if (e->d_params || e->d_st64 || e->d_stats || e->d_io) {
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(e->d_params);
+    (void)hipFree(e->d_st64);
+    (void)hipFree(e->d_st32);
+    (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_io);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+  }
+  delete e;
+}
+
+int af_engine_reset(af_engine *e) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (e->started) {
+    AF_HIP(hipSetDevice(e->device));
+    AF_HIP(hipDeviceSynchronize());
+  }
+  e->started = false;
+  e->params_dirty = true;
+  e->samples_processed = 0;
+  e->last_blocks = 0;
+  return AF_OK;
+}
+
+int32_t af_engine_n_streams(const af_engine *e) { return e ? e->n_streams : 0; }
+
+#define AF_SETTER(expr)              \
+  do {                               \
+    int rc__ = require_config(e);    \
+    if (rc__) return rc__;           \
+    expr;                            \
+    return AF_OK;                    \
+  } while (0)
+
+int af_engine_set_deesser_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.deesser_enabled = e->proto.deesser.enabled = on != 0); }
+int af_engine_set_eq_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.eq_enabled = e->proto.eq.enabled = on != 0); }
+int af_engine_set_compressor_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor_enabled = e->proto.compressor.enabled = on != 0); }
+int af_engine_set_limiter_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.limiter_enabled = e->proto.limiter.enabled = on != 0); }
+int af_engine_set_eq_before_deesser(af_engine *e, int32_t on) { AF_SETTER(e->proto.eq_before_deesser = on != 0); }
+int af_engine_set_input_scrub_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.input_scrub = on != 0); }
+int af_engine_set_input_clamp_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.input_clamp = on != 0); }
+int af_engine_set_prefilter_enabled(af_engine *e, int32_t on, int32_t hp) {
+  AF_SETTER((e->proto.dc_block = on != 0, e->proto.pre_highpass = on != 0 && hp != 0));
+}
+int af_engine_set_control_block_samples(af_engine *e, int32_t n) {
+  if (n < 1 || n > 8192) return fail(AF_ERR_INVALID_ARGUMENT, "control block must be in [1, 8192] samples");
+  AF_SETTER(e->proto.control_block = n);
+}
+
+int af_eq_set_band_frequency(af_engine *e, int32_t band, double hz) {
+  if (int rc = check_band(band)) return rc;
+  AF_SETTER(e->proto.eq.set_band_frequency(band, hz));
+}
+int af_eq_set_band_gain(af_engine *e, int32_t band, double db) {
+  if (int rc = check_band(band)) return rc;
+  AF_SETTER(e->proto.eq.set_band_gain(band, db));
+}
+int af_eq_set_band_q(af_engine *e, int32_t band, double q) {
+  if (int rc = check_band(band)) return rc;
+  AF_SETTER(e->proto.eq.set_band_q(band, q));
+}
+int af_eq_set_band_config(af_engine *e, int32_t band, const af_eq_band_config *c) {
+  if (int rc = check_band(band)) return rc;
+  if (!c) return fail(AF_ERR_INVALID_ARGUMENT, "config is null");
+  AF_SETTER(e->proto.eq.set_band_config(band, to_cfg(*c)));
+}
+int af_eq_reset(af_engine *e) { AF_SETTER(e->proto.eq.reset()); }
+int af_eq_band_config_validate(const af_eq_band_config *c, int32_t index, double sample_rate) {
+  if (!c) return fail(AF_ERR_INVALID_ARGUMENT, "config is null");
+  if (c->filter_type < 0 || c->filter_type > 5)
+    return fail(AF_ERR_INVALID_ARGUMENT, "band %d has unsupported EQ filter type id: %d", index, c->filter_type);
+  const std::string msg = af::eq_validate(to_cfg(*c), index, sample_rate);
+  if (!msg.empty()) return fail(AF_ERR_INVALID_ARGUMENT, "%s", msg.c_str());
+  return AF_OK;
+}
+
+int af_compressor_set_threshold(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_threshold(v)); }
+int af_compressor_set_ratio(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_ratio(v)); }
+int af_compressor_set_attack_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_attack_time(v)); }
+int af_compressor_set_release_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_release_time(v)); }
+int af_compressor_set_makeup_gain(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_makeup_gain(v)); }
+int af_compressor_set_adaptive_release(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_adaptive_release(on != 0)); }
+int af_compressor_set_base_release_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_base_release_time(v)); }
+int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_auto_makeup_enabled(on != 0)); }
+int af_compressor_set_target_lufs(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_target_lufs(v)); }
+int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_sidechain_highpass_enabled(on != 0)); }
+
+int af_limiter_set_ceiling(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_ceiling(v)); }
+int af_limiter_set_release_time(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_release_time(v)); }
+int af_limiter_set_lookahead_ms(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_lookahead_ms(v)); }
+double af_limiter_ceiling_db(const af_engine *e) { return e ? e->proto.limiter.ceiling_db : 0.0; }
+int32_t af_limiter_lookahead_samples(const af_engine *e) { return e ? e->proto.limiter.lookahead_samples : 0; }
+
+int af_true_peak_limiter_set_release_ms(af_engine *e, float ms) { AF_SETTER(e->proto.tp_limiter.set_release_ms(ms)); }
+
+int af_deesser_set_auto_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.deesser.auto_enabled = on != 0); }
+int af_deesser_set_auto_amount(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_auto_amount(v)); }
+int af_deesser_set_low_cut_hz(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_low_cut_hz(v)); }
+int af_deesser_set_high_cut_hz(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_high_cut_hz(v)); }
+int af_deesser_set_threshold_db(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_threshold_db(v)); }
+int af_deesser_set_ratio(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_ratio(v)); }
+int af_deesser_set_attack_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_attack_ms(v)); }
+int af_deesser_set_release_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_release_ms(v)); }
+int af_deesser_set_max_reduction_db(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_max_reduction_db(v)); }
+
+int af_engine_set_kernel(af_engine *e, int32_t kernel) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_PHASED) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  e->kernel = kernel;
+  return AF_OK;
+}
+int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  e->timing = on != 0;
+  return AF_OK;
+}
+
+int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t n_samples, int64_t stream_stride,
+                             int32_t layout, void *hip_stream) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (n_samples < 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+  if (layout != AF_LAYOUT_STREAM_MAJOR && layout != AF_LAYOUT_TIME_MAJOR)
+    return fail(AF_ERR_INVALID_ARGUMENT, "unknown layout %d", layout);
+  if (n_samples > 0 && (!in || !out)) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
+  const int64_t min_stride = layout == AF_LAYOUT_STREAM_MAJOR ? n_samples : e->n_streams;
+  if (stream_stride < min_stride) return fail(AF_ERR_INVALID_ARGUMENT, "stream_stride %lld is smaller than %lld",
+                                              (long long)stream_stride, (long long)min_stride);
+  if (int rc = ensure_started(e)) return rc;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  e->last_stream = stream;
+  const int cb = e->host_params.control_block;
+  const int64_t blocks = (n_samples + cb - 1) / cb;
+  e->last_blocks = blocks;
+  e->last_kernel_ms = 0.0;
+  e->last_launches = 0;
+  if (n_samples == 0) return AF_OK;
+  const int64_t rows = blocks * e->n_streams;
+  if (rows > e->stats_capacity) {
+    if (e->d_stats) {
+      AF_HIP(hipStreamSynchronize(stream));
+      AF_HIP(hipFree(e->d_stats));
+    }
+    AF_HIP(hipMalloc(&e->d_stats, sizeof(af::BlockStats) * rows));
+    e->stats_capacity = rows;
+  }
+  if (e->params_dirty) {
+    AF_HIP(hipMemcpyAsync(e->d_params, &e->host_params, sizeof(af::ChainParams), hipMemcpyHostToDevice, stream));
+    // the host struct may change right after the launch (crossfade bookkeeping): wait for the copy
+    AF_HIP(hipStreamSynchronize(stream));
+    e->params_dirty = false;
+  }
+  af::LaunchArgs a{};
+  a.params = e->d_params;
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.in = in;
+  a.out = out;
+  a.stats = e->d_stats;
+  a.n_samples = n_samples;
+  a.stream_stride = stream_stride;
+  a.samples_before = e->samples_processed;
+  a.n_streams = e->n_streams;
+  a.layout = layout;
+  if (e->timing) {
+    if (!e->ev_start) {
+      AF_HIP(hipEventCreate(&e->ev_start));
+      AF_HIP(hipEventCreate(&e->ev_stop));
+    }
+    AF_HIP(hipEventRecord(e->ev_start, stream));
+  }
+  AF_HIP(af::launch_chain_lane(a, e->host_params.lim.lookahead_samples, stream));
+  e->last_launches = 1;
+  if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
+  e->samples_processed += n_samples;
+  advance_crossfades(e, n_samples);
+  return AF_OK;
+}
+
+int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_samples, int32_t layout) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (n_samples < 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+  if (n_samples > 0 && (!in || !out)) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
+  if (int rc = ensure_started(e)) return rc;
+  const int64_t total = n_samples * e->n_streams;
+  if (total > e->io_capacity) {
+    if (e->d_io) AF_HIP(hipFree(e->d_io));
+    AF_HIP(hipMalloc(&e->d_io, sizeof(float) * total));
+    e->io_capacity = total;
+  }
+  if (total > 0) AF_HIP(hipMemcpy(e->d_io, in, sizeof(float) * total, hipMemcpyHostToDevice));
+  const int64_t stride = layout == AF_LAYOUT_STREAM_MAJOR ? n_samples : e->n_streams;
+  if (int rc = af_engine_process_device(e, e->d_io, e->d_io, n_samples, stride, layout, nullptr)) return rc;
+  AF_HIP(hipStreamSynchronize(nullptr));
+  if (total > 0) AF_HIP(hipMemcpy(out, e->d_io, sizeof(float) * total, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+int af_engine_synchronize(af_engine *e) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (!e->started) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipStreamSynchronize(e->last_stream));
+  return AF_OK;
+}
+
+int64_t af_engine_last_block_count(const af_engine *e) { return e ? e->last_blocks : 0; }
+int64_t af_engine_samples_processed(const af_engine *e) { return e ? e->samples_processed : 0; }
+
+int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capacity) {
+  if (!e || !out) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  const int64_t rows = e->last_blocks * e->n_streams;
+  if (capacity < rows) return fail(AF_ERR_INVALID_ARGUMENT, "capacity %lld < %lld rows", (long long)capacity, (long long)rows);
+  if (rows == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipStreamSynchronize(e->last_stream));
+  AF_HIP(hipMemcpy(out, e->d_stats, sizeof(af::BlockStats) * rows, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches) {
+  if (!e || !ms) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  *ms = 0.0;
+  if (launches) *launches = e->last_launches;
+  if (!e->timing || !e->ev_start || e->last_launches == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipEventSynchronize(e->ev_stop));
+  float t = 0.0f;
+  AF_HIP(hipEventElapsedTime(&t, e->ev_start, e->ev_stop));
+  *ms = (double)t;
+  return AF_OK;
+}
+
+// ---- stateless helpers -----------------------------------------------------------------
+int af_eq_magnitude_response(const double *freqs, size_t n, const double bands[10][3], double sample_rate,
+                             double *out_db) {  // lib.rs:99-150
+  if (!std::isfinite(sample_rate) || sample_rate <= 0.0)
+    return fail(AF_ERR_INVALID_ARGUMENT, "sample_rate must be finite and positive");
+  if (!bands || (!freqs && n) || (!out_db && n)) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  const double nyquist = sample_rate / 2.0;
+  for (int i = 0; i < af::kNumBands; ++i) {
+    const double f = bands[i][0], g = bands[i][1], q = bands[i][2];
+    if (!std::isfinite(f) || f <= 0.0 || f >= nyquist)
+      return fail(AF_ERR_INVALID_ARGUMENT, "band %d frequency must be between 0 Hz and Nyquist", i);
+    if (!std::isfinite(g)) return fail(AF_ERR_INVALID_ARGUMENT, "band %d gain must be finite", i);
+    if (!std::isfinite(q) || q <= 0.0) return fail(AF_ERR_INVALID_ARGUMENT, "band %d Q must be finite and positive", i);
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(freqs[i]) || freqs[i] < 0.0 || freqs[i] > nyquist)
+      return fail(AF_ERR_INVALID_ARGUMENT, "response frequencies must be finite and between 0 Hz and Nyquist");
+  af::EqProto eq(sample_rate);
+  for (int i = 0; i < af::kNumBands; ++i) {
+    eq.set_band_frequency(i, bands[i][0]);
+    eq.set_band_gain(i, bands[i][1]);
+    eq.set_band_q(i, bands[i][2]);
+  }
+  for (size_t i = 0; i < n; ++i) out_db[i] = eq.magnitude_db(freqs[i]);
+  return AF_OK;
+}
+
+int af_eq_magnitude_response_v2(const double *freqs, size_t n, const af_eq_band_config bands[10], double sample_rate,
+                                double *out_db) {  // lib.rs:152-212
+  if (!std::isfinite(sample_rate) || sample_rate <= 0.0)
+    return fail(AF_ERR_INVALID_ARGUMENT, "sample_rate must be finite and positive");
+  if (!bands || (!freqs && n) || (!out_db && n)) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  for (int i = 0; i < af::kNumBands; ++i)
+    if (int rc = af_eq_band_config_validate(&bands[i], i, sample_rate)) return rc;
+  const double nyquist = sample_rate / 2.0;
+  for (size_t i = 0; i < n; ++i)
+    if (!std::isfinite(freqs[i]) || freqs[i] < 0.0 || freqs[i] > nyquist)
+      return fail(AF_ERR_INVALID_ARGUMENT, "response frequencies must be finite and between 0 Hz and Nyquist");
+  af::EqProto eq(sample_rate);
+  for (int i = 0; i < af::kNumBands; ++i) eq.set_band_config(i, to_cfg(bands[i]));
+  for (size_t i = 0; i < n; ++i) out_db[i] = eq.magnitude_db(freqs[i]);
+  return AF_OK;
+}
+
+int af_engine_eq_magnitude_response(const af_engine *e, const double *freqs, size_t n, double *out_db) {
+  if (!e || (!freqs && n) || (!out_db && n)) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  for (size_t i = 0; i < n; ++i) out_db[i] = e->proto.eq.magnitude_db(freqs[i]);
+  return AF_OK;
+}
+
+}  // extern "C"

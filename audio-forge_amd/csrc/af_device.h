@@ -1,0 +1,154 @@
+// af_device.h -- plain structs shared by the host configuration mirror and the HIP kernels.
+//
+// Everything a stream needs that is identical for all streams of an engine (coefficients,
+// time constants, switches) lives in ChainParams and is read through scalar loads; what
+// differs per stream (filter memories, envelopes, delay lines) lives in two
+// structure-of-arrays state planes, f64 and f32, laid out [field][stream] so that lane i
+// of a wavefront touches consecutive addresses.
+#pragma once
+#include <stdint.h>
+
+namespace af {
+
+constexpr int kNumBands = 10;
+constexpr int kMaxSectionsPerBand = 4;
+constexpr int kMaxEqSections = kNumBands * kMaxSectionsPerBand;
+constexpr int kTpTaps = 32;
+constexpr int kTpDelay = 20;
+constexpr int kMaxLookahead = 1024;
+constexpr int kTile = 64;          // samples per LDS tile (per stream)
+constexpr int kLanes = 64;         // streams per workgroup in the lane-per-stream kernel
+constexpr int kLdsLookaheadMax = 127;  // limiter ring kept in LDS up to this lookahead
+
+struct BiquadCoef {
+  double b0, b1, b2, a1, a2;
+};
+
+// One second-order section with the reference's parallel-state coefficient crossfade
+// (dsp/biquad.rs:39-66).  xf_* are identical for all streams because streams advance in
+// lock step.
+struct SectionParams {
+  BiquadCoef active;
+  BiquadCoef pending;
+  int32_t xf_total;
+  int32_t xf_remaining;  // at the start of the launch
+};
+
+// dsp/compressor.rs:46-129, the parameter half
+struct CompressorParams {
+  double threshold_db, ratio, knee_db;
+  double attack_coeff, detector_release_coeff, rms_coeff;
+  double release_smoothing_coeff, base_release_ms;
+  double band_env_coeff;        // tc(SIDECHAIN_BAND_ENV_MS), compressor.rs:429
+  double fast_release_coeff;    // tc(50 ms),  compressor.rs:482-483
+  double slow_charge_coeff;     // tc(250 ms), compressor.rs:484-485
+  double slow_release_coeff;    // tc(400 ms), compressor.rs:486-487
+  double sidechain_highpass_coeff;
+  double makeup_gain_db, makeup_smoothing_coeff, makeup_silence_relax_coeff;
+  double speech_activity_smoothing_coeff, target_lufs, noise_reference_reliability;
+  double sample_rate;
+  int32_t adaptive_release, sidechain_highpass_enabled, auto_makeup_enabled, pad;
+};
+
+// dsp/limiter.rs:71-97
+struct LimiterParams {
+  double ceiling_db, ceiling_linear, release_coeff;
+  int32_t lookahead_samples, pad;
+};
+
+// dsp/true_peak.rs:250-264
+struct TruePeakParams {
+  float ceiling_linear, release_coeff;
+};
+
+// dsp/deesser.rs:88-107 (+ per band static data)
+struct DeEsserBandParams {
+  BiquadCoef detector_hp, detector_lp;
+  double dyn_sin_omega, dyn_cos_omega, dyn_alpha;  // dynamic_eq: fixed centre & Q
+};
+struct DeEsserParams {
+  double attack_coeff, release_coeff, detector_attack_coeff, detector_release_coeff;
+  double max_reduction_db, threshold_db, ratio, auto_amount;
+  double baseline_fall, baseline_rise, baseline_inactive;
+  int32_t auto_enabled, pad;
+  DeEsserBandParams bands[3];
+};
+
+enum ChainFlags : uint32_t {
+  kFlagDeesser = 1u << 0,
+  kFlagEq = 1u << 1,
+  kFlagCompressor = 1u << 2,
+  kFlagLimiter = 1u << 3,
+  kFlagEqBeforeDeesser = 1u << 4,
+  kFlagInputScrub = 1u << 5,   // python_api.rs:517-520
+  kFlagInputClamp = 1u << 6,   // routing.rs:802-823
+  kFlagDcBlock = 1u << 7,      // routing.rs:826-843
+  kFlagPreHighpass = 1u << 8,
+};
+
+struct ChainParams {
+  uint32_t flags;
+  int32_t n_eq_sections;
+  int32_t control_block;
+  int32_t pad;
+  BiquadCoef pre_hp;  // Biquad(HighPass, 80 Hz, Q 0.707), processor.rs:74-76
+  SectionParams eq[kMaxEqSections];
+  CompressorParams comp;
+  LimiterParams lim;
+  TruePeakParams tp;
+  DeEsserParams deesser;
+};
+
+// ---- per-stream state planes -------------------------------------------------------
+// f64 plane field indices
+enum F64Field : int {
+  kPreZ1 = 0, kPreZ2,
+  kCompScPrevIn, kCompScPrevOut, kCompLowEnv, kCompVoicedEnv, kCompPresenceEnv, kCompPlosive,
+  kCompPeakEnvDb, kCompRmsEnvSq, kCompGr, kCompFastEnv, kCompSlowEnv,
+  kCompCurReleaseMs, kCompTargetReleaseMs, kCompReleaseCoeff, kCompSmoothedMakeup,
+  kCompActivityScore, kCompActivityReliability, kCompCurrentLufs,
+  kLimGain,
+  kDeBroadbandEnv, kDeCurrentReduction, kDeConfidence,
+  // per de-esser band (x3): env, confidence, baseline, reduction, dyn gain, hp z1 z2, lp z1 z2, dyn z1 z2
+  kDeBand0,
+  kDeBandStride = 11,
+  kEqBase = kDeBand0 + 3 * kDeBandStride,  // then 4 per section: z1 z2 pz1 pz2
+  kF64Fixed = kEqBase
+};
+inline int f64_field_count(int n_sections) { return kF64Fixed + 4 * n_sections; }
+
+// f32 plane field indices
+enum F32Field : int {
+  kDcX1 = 0, kDcY1,
+  kTpGain,
+  kLimPrefix,            // running prefix max of the current van-Herk block
+  kTpInHist,             // 32 rows: last 32 true-peak-limiter inputs (oldest first)
+  kTpOutHist = kTpInHist + kTpTaps,  // 32 rows: last 32 outputs
+  kLimRing = kTpOutHist + kTpTaps,   // W rows ring + W rows suffix-max, W = lookahead+1
+  kF32Fixed = kLimRing
+};
+inline int f32_field_count(int lookahead) { return kF32Fixed + 2 * (lookahead + 1); }
+
+// ---- per-block statistics row (== af_block_stats in include/audioforge_mi.h) --------
+struct BlockStats {
+  float input_sample_peak, output_sample_peak, tp_limiter_input_peak, output_true_peak;
+  float limiter_peak_gr_db, tp_limiter_gr_db, compressor_gr_db, deesser_gr_db;
+  double input_square_sum, output_square_sum;
+  uint32_t tp_limited_events, non_finite_output;
+};
+
+struct LaunchArgs {
+  const ChainParams *params;  // device
+  double *st64;               // [f64 fields][n_streams]
+  float *st32;                // [f32 fields][n_streams]
+  const float *in;
+  float *out;
+  BlockStats *stats;          // [blocks][n_streams]
+  int64_t n_samples;
+  int64_t stream_stride;
+  int64_t samples_before;     // samples processed by earlier launches (van-Herk phase)
+  int32_t n_streams;
+  int32_t layout;
+};
+
+}  // namespace af

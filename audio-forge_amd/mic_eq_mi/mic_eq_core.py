@@ -1,0 +1,488 @@
+"""Drop-in for the offline operator surface of ``mic_eq.mic_eq_core`` on the MI355X engine.
+
+Function names, argument meaning, returned dict keys and error behaviour follow the PyO3
+module of the reference (rust-core/src/lib.rs:99-350, audio/processor/python_api.rs:118-714,
+typed in python/mic_eq/mic_eq_core.pyi:202-258).  The audio path is the HIP engine behind
+``libaudioforge_mi.so``; this file only (a) replays the reference's setter sequence on an
+engine and (b) folds the per-block rows the kernels emit into the dict statistics
+(python_api.rs:578-713).  There is no CPU audio path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Any, Mapping, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlockStats, EqBandConfig
+
+NUM_BANDS = 10
+EQ_TYPE_IDS = {"low_shelf": 0, "bell": 1, "high_shelf": 2, "notch": 3, "high_pass": 4, "low_pass": 5}
+CAREFUL_OUTPUT_CEILING_DB = -1.5  # audio/processor/control.rs:772
+STATS_DTYPE = np.dtype(
+    [
+        ("input_sample_peak", "<f4"),
+        ("output_sample_peak", "<f4"),
+        ("true_peak_limiter_input_peak", "<f4"),
+        ("output_true_peak", "<f4"),
+        ("limiter_peak_gain_reduction_db", "<f4"),
+        ("true_peak_limiter_gain_reduction_db", "<f4"),
+        ("compressor_gain_reduction_db", "<f4"),
+        ("deesser_gain_reduction_db", "<f4"),
+        ("input_square_sum", "<f8"),
+        ("output_square_sum", "<f8"),
+        ("true_peak_limited_events", "<u4"),
+        ("non_finite_output", "<u4"),
+    ]
+)
+assert STATS_DTYPE.itemsize == C.sizeof(BlockStats)
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------------------- engine
+class Engine:
+    """N independent reference chains (OfflineDspBlockProcessor) resident on one GPU.
+
+    Setter methods are the C ABI entry points with the ``af_`` prefix dropped, e.g.
+    ``engine.compressor_set_threshold(-20.0)`` or ``engine.eq_set_band_gain(2, 3.0)``.
+    """
+
+    def __init__(self, sample_rate: float = 48_000.0, n_streams: int = 1, device: int = 0):
+        self._lib = _lib.load()
+        handle = C.c_void_p()
+        _lib.check(self._lib.af_engine_create(float(sample_rate), int(n_streams), int(device), C.byref(handle)))
+        self._h = handle
+        self.sample_rate = float(sample_rate)
+        self.n_streams = int(n_streams)
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.af_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __getattr__(self, name: str):
+        # engine.<x>(...) -> af_<x>(handle, ...) / af_engine_<x>(handle, ...)
+        for symbol in (f"af_{name}", f"af_engine_{name}"):
+            if symbol in _lib.SIGNATURES:
+                fn = getattr(self._lib, symbol)
+                is_status = symbol not in _lib.VALUE_FUNCTIONS
+
+                def call(*args, _fn=fn, _is_status=is_status):
+                    rc = _fn(self._h, *args)
+                    if _is_status:
+                        _lib.check(rc)
+                        return None
+                    return rc
+
+                return call
+        raise AttributeError(name)
+
+    def eq_set_band_config_tuple(self, band: int, cfg: tuple) -> None:
+        name, freq, gain, q, slope, enabled = cfg
+        c = EqBandConfig(EQ_TYPE_IDS[name], float(freq), float(gain), float(q), int(slope), int(bool(enabled)))
+        _lib.check(self._lib.af_eq_set_band_config(self._h, band, C.byref(c)))
+
+    # -- processing ---------------------------------------------------------------
+    def process(self, audio: np.ndarray, layout: int = _lib.LAYOUT_STREAM_MAJOR) -> np.ndarray:
+        """Host arrays: [n_streams, n] (stream-major) or [n, n_streams] (time-major) float32."""
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        if a.ndim == 1:
+            a = a.reshape(1, -1) if layout == _lib.LAYOUT_STREAM_MAJOR else a.reshape(-1, 1)
+        n_streams, n = (a.shape if layout == _lib.LAYOUT_STREAM_MAJOR else a.shape[::-1])
+        if n_streams != self.n_streams:
+            raise ValueError(f"expected {self.n_streams} streams, got {n_streams}")
+        out = np.empty_like(a)
+        fp = C.POINTER(C.c_float)
+        _lib.check(self._lib.af_engine_process_host(self._h, a.ctypes.data_as(fp), out.ctypes.data_as(fp), int(n), layout))
+        return out
+
+    def process_device(self, in_ptr: int, out_ptr: int, n_samples: int, stream_stride: int,
+                       layout: int = _lib.LAYOUT_STREAM_MAJOR, hip_stream: int = 0) -> None:
+        """Device pointers (e.g. ``tensor.data_ptr()``); asynchronous on ``hip_stream``."""
+        _lib.check(self._lib.af_engine_process_device(self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), int(n_samples),
+                                                      int(stream_stride), int(layout), C.c_void_p(hip_stream)))
+
+    def block_stats(self) -> np.ndarray:
+        """Structured array [blocks, n_streams] of the last process call."""
+        blocks = int(self._lib.af_engine_last_block_count(self._h))
+        rows = np.zeros((blocks, self.n_streams), dtype=STATS_DTYPE)
+        if blocks:
+            _lib.check(self._lib.af_engine_read_block_stats(self._h, rows.ctypes.data_as(C.POINTER(BlockStats)), rows.size))
+        return rows
+
+    def last_kernel_ms(self) -> tuple[float, int]:
+        ms, launches = C.c_double(0.0), C.c_int32(0)
+        _lib.check(self._lib.af_engine_last_kernel_ms(self._h, C.byref(ms), C.byref(launches)))
+        return ms.value, launches.value
+
+
+# ---------------------------------------------------------------------- argument checks
+def _audio_1d(audio) -> np.ndarray:
+    if not isinstance(audio, np.ndarray) or audio.dtype != np.float32 or audio.ndim != 1:
+        raise TypeError("audio must be a 1-D numpy.float32 array")
+    if not audio.flags.c_contiguous:
+        raise ValueError("audio must be a contiguous float32 array")
+    return audio
+
+
+def _bands_v2(bands, sample_rate: float):
+    """parse_eq_v2_bands, lib.rs:154-189."""
+    if not np.isfinite(sample_rate) or sample_rate <= 0.0:
+        raise ValueError("sample_rate must be finite and positive")
+    if len(bands) != NUM_BANDS:
+        raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
+    arr = (EqBandConfig * NUM_BANDS)()
+    lib = _lib.load()
+    for index, (name, freq, gain, q, slope, enabled) in enumerate(bands):
+        if name not in EQ_TYPE_IDS:
+            raise ValueError(f"band {index} has unsupported EQ filter type: {name}")
+        arr[index] = EqBandConfig(EQ_TYPE_IDS[name], float(freq), float(gain), float(q), int(slope), int(bool(enabled)))
+        _lib.check(lib.af_eq_band_config_validate(C.byref(arr[index]), index, float(sample_rate)))
+    return arr
+
+
+def _get(settings: Mapping[str, object] | None, key: str, default):
+    if settings is not None and key in settings and settings[key] is not None:
+        value = settings[key]
+        if isinstance(default, bool):
+            if not isinstance(value, (bool, np.bool_)):
+                raise TypeError(f"settings[{key!r}] must be a bool")
+            return bool(value)
+        return float(value)
+    return default
+
+
+# ---------------------------------------------------- python_api.rs:54-111 statistics
+def _linear_to_db(value) -> np.float32:
+    return f32(20.0) * np.log10(np.maximum(f32(value), f32(1.0e-12)), dtype=np.float32)
+
+
+def _percentile(values: np.ndarray, percentile: float) -> np.float32:
+    values = np.sort(np.asarray(values, dtype=np.float32))
+    if values.size == 0:
+        return f32(0.0)
+    position = f32(values.size - 1) * f32(min(max(percentile, 0.0), 1.0))
+    lower = int(np.floor(position))
+    upper = int(np.ceil(position))
+    if lower == upper:
+        return values[lower]
+    fraction = position - f32(lower)
+    return values[lower] + fraction * (values[upper] - values[lower])
+
+
+def _pumping_score(trace: np.ndarray, cadence_hz: float) -> np.float32:
+    trace = np.asarray(trace, dtype=np.float32)
+    if trace.size < 3 or not np.isfinite(cadence_hz) or cadence_hz <= 0.0:
+        return f32(0.0)
+    pi = f32(np.pi)
+    dt = f32(1.0) / f32(cadence_hz)
+    highpass_rc = f32(1.0) / (f32(2.0) * pi * f32(2.0))
+    lowpass_rc = f32(1.0) / (f32(2.0) * pi * f32(8.0))
+    highpass_alpha = highpass_rc / (highpass_rc + dt)
+    lowpass_alpha = dt / (lowpass_rc + dt)
+    previous = trace[0]
+    highpass = f32(0.0)
+    bandpass = f32(0.0)
+    bandpass_abs = np.empty(trace.size - 1, dtype=np.float32)
+    deltas = np.empty(trace.size - 1, dtype=np.float32)
+    for i in range(1, trace.size):
+        value = trace[i]
+        if not np.isfinite(value):
+            return f32(np.inf)
+        highpass = highpass_alpha * (highpass + value - previous)
+        bandpass = bandpass + lowpass_alpha * (highpass - bandpass)
+        bandpass_abs[i - 1] = abs(bandpass)
+        deltas[i - 1] = abs(value - previous)
+        previous = value
+    robust_limit = _percentile(bandpass_abs, 0.95)
+    total = f32(0.0)
+    for v in np.minimum(bandpass_abs, robust_limit):
+        total = total + v * v
+    robust_rms = np.sqrt(total / f32(bandpass_abs.size))
+    return f32(robust_rms + _percentile(deltas, 0.95))
+
+
+def chain_diagnostics(rows: np.ndarray, block_lengths: np.ndarray, effective_ceiling_db: float) -> dict[str, Any]:
+    """Fold one stream's per-block rows into the dict of python_api.rs:578-713."""
+    n_rows = rows.shape[0]
+    in_sq_total = 0.0
+    out_sq_total = 0.0
+    for k in range(n_rows):  # sequential f64 accumulation order of python_api.rs:519-571
+        in_sq_total += float(rows["input_square_sum"][k])
+        out_sq_total += float(rows["output_square_sum"][k])
+    samples = int(block_lengths.sum())
+    input_rms = f32(np.sqrt(in_sq_total / samples)) if samples > 0 else f32(0.0)
+    output_rms = f32(np.sqrt(out_sq_total / samples)) if samples > 0 else f32(0.0)
+    lengths = block_lengths.astype(np.float64)
+    block_in_rms = np.sqrt(rows["input_square_sum"] / lengths).astype(np.float32)
+    block_out_rms = np.sqrt(rows["output_square_sum"] / lengths).astype(np.float32)
+    in_db = _linear_to_db(block_in_rms)
+    out_db = _linear_to_db(block_out_rms)
+    comp = rows["compressor_gain_reduction_db"].astype(np.float32)
+    dees = rows["deesser_gain_reduction_db"].astype(np.float32)
+
+    def fmax(field):
+        return f32(rows[field].max()) if n_rows else f32(0.0)
+
+    input_sample_peak = max(f32(0.0), fmax("input_sample_peak"))
+    output_sample_peak = max(f32(0.0), fmax("output_sample_peak"))
+    pre_limiter_true_peak = max(f32(0.0), fmax("true_peak_limiter_input_peak"))
+    output_true_peak = max(f32(0.0), fmax("output_true_peak"))
+    output_sample_peak_db = _linear_to_db(output_sample_peak)
+    pre_limiter_true_peak_db = _linear_to_db(pre_limiter_true_peak)
+    output_true_peak_db = _linear_to_db(output_true_peak)
+    ceiling = f32(effective_ceiling_db)
+
+    input_floor_db = _percentile(in_db, 0.20)
+    input_p90_db = _percentile(in_db, 0.90)
+    active_threshold_db = max(max(input_floor_db + f32(6.0), input_p90_db - f32(24.0)), f32(-60.0))
+    active = in_db >= active_threshold_db
+    active_comp = np.maximum(comp[active], f32(0.0))
+    active_dees = np.maximum(dees[active], f32(0.0))
+    if active_comp.size < 3:
+        active_comp = np.maximum(comp, f32(0.0))
+        active_dees = np.maximum(dees, f32(0.0))
+    active_block_count = int(active_comp.size)
+    active_ratio = f32(np.count_nonzero(active_comp >= f32(0.10))) / f32(active_block_count) if active_block_count else f32(0.0)
+    audible = in_db > f32(-100.0)
+    active_output_gain = _percentile((out_db - in_db)[active & audible], 0.50)
+    silence_level_delta = _percentile((out_db - in_db)[(~active) & audible], 0.50)
+    silence_output_gain = _percentile(-np.maximum(comp[~active], f32(0.0)), 0.50)
+    pumping = _pumping_score(np.maximum(comp, f32(0.0)), 50.0)
+    return {
+        "input_sample_peak_db": float(_linear_to_db(input_sample_peak)),
+        "input_rms_db": float(_linear_to_db(input_rms)),
+        "output_sample_peak_db": float(output_sample_peak_db),
+        "pre_limiter_true_peak_db": float(pre_limiter_true_peak_db),
+        "output_true_peak_db": float(output_true_peak_db),
+        "output_rms_db": float(_linear_to_db(output_rms)),
+        "limiter_effective_ceiling_db": float(ceiling),
+        "sample_headroom_db": float(ceiling - output_sample_peak_db),
+        "pre_limiter_true_peak_headroom_db": float(ceiling - pre_limiter_true_peak_db),
+        "true_peak_headroom_db": float(ceiling - output_true_peak_db),
+        "limiter_gain_reduction_db": float(max(f32(0.0), fmax("limiter_peak_gain_reduction_db"))),
+        "true_peak_limiter_gain_reduction_db": float(max(f32(0.0), fmax("true_peak_limiter_gain_reduction_db"))),
+        "true_peak_limited_events": int(rows["true_peak_limited_events"].sum()),
+        "compressor_gain_reduction_db": float(max(f32(0.0), fmax("compressor_gain_reduction_db"))),
+        "deesser_gain_reduction_db": float(max(f32(0.0), fmax("deesser_gain_reduction_db"))),
+        "compressor_gain_reduction_median_db": float(_percentile(active_comp, 0.50)),
+        "compressor_gain_reduction_p95_db": float(_percentile(active_comp, 0.95)),
+        "compressor_gain_reduction_active_ratio": float(active_ratio),
+        "active_output_gain_db": float(active_output_gain),
+        "silence_output_gain_db": float(silence_output_gain),
+        "silence_level_delta_db": float(silence_level_delta),
+        "compressor_pumping_score_db": float(pumping),
+        "non_finite_output": bool(rows["non_finite_output"].any()),
+        "deesser_gain_reduction_median_db": float(_percentile(active_dees, 0.50)),
+        "deesser_gain_reduction_p95_db": float(_percentile(active_dees, 0.95)),
+        "analysis_block_ms": 20.0,
+        "active_analysis_threshold_db": float(active_threshold_db),
+        "active_analysis_block_count": active_block_count,
+        "processed_samples": samples,
+    }
+
+
+# ------------------------------------------------------------ simulate_auto_eq_chain
+def configure_auto_eq_chain(engine: Engine, sample_rate: float, bands, settings: Mapping[str, object] | None) -> float:
+    """Replay python_api.rs:400-487 on `engine`; returns the effective limiter ceiling (dB, f32)."""
+    engine.set_eq_enabled(1)
+    if settings is not None and settings.get("eq_bands_v2") is not None:
+        arr = _bands_v2(list(settings["eq_bands_v2"]), sample_rate)
+        lib = _lib.load()
+        for index in range(NUM_BANDS):
+            _lib.check(lib.af_eq_set_band_config(engine._h, index, C.byref(arr[index])))
+        engine.eq_reset()
+    else:
+        for index, (frequency, gain_db, q) in enumerate(bands):
+            engine.eq_set_band_frequency(index, float(frequency))
+            engine.eq_set_band_gain(index, float(gain_db))
+            engine.eq_set_band_q(index, float(q))
+    deesser_enabled = _get(settings, "deesser_enabled", False)
+    engine.set_eq_before_deesser(int(_get(settings, "eq_before_deesser", False)))
+    engine.set_deesser_enabled(int(deesser_enabled))
+    if deesser_enabled:
+        engine.deesser_set_auto_enabled(int(_get(settings, "deesser_auto_enabled", True)))
+        engine.deesser_set_auto_amount(_get(settings, "deesser_auto_amount", 0.5))
+        engine.deesser_set_low_cut_hz(_get(settings, "deesser_low_cut_hz", 4000.0))
+        engine.deesser_set_high_cut_hz(_get(settings, "deesser_high_cut_hz", 11_000.0))
+        engine.deesser_set_threshold_db(_get(settings, "deesser_threshold_db", -28.0))
+        engine.deesser_set_ratio(_get(settings, "deesser_ratio", 4.0))
+        engine.deesser_set_attack_ms(_get(settings, "deesser_attack_ms", 2.0))
+        engine.deesser_set_release_ms(_get(settings, "deesser_release_ms", 80.0))
+        engine.deesser_set_max_reduction_db(_get(settings, "deesser_max_reduction_db", 6.0))
+    compressor_enabled = _get(settings, "compressor_enabled", True)
+    engine.set_compressor_enabled(int(compressor_enabled))
+    if compressor_enabled:
+        engine.compressor_set_threshold(_get(settings, "compressor_threshold_db", -20.0))
+        engine.compressor_set_ratio(_get(settings, "compressor_ratio", 4.0))
+        engine.compressor_set_attack_time(_get(settings, "compressor_attack_ms", 10.0))
+        engine.compressor_set_release_time(_get(settings, "compressor_release_ms", 200.0))
+        engine.compressor_set_makeup_gain(_get(settings, "compressor_makeup_gain_db", 0.0))
+        engine.compressor_set_adaptive_release(int(_get(settings, "compressor_adaptive_release", False)))
+        engine.compressor_set_base_release_time(_get(settings, "compressor_base_release_ms", 50.0))
+        engine.compressor_set_auto_makeup_enabled(int(_get(settings, "compressor_auto_makeup_enabled", False)))
+        engine.compressor_set_target_lufs(_get(settings, "compressor_target_lufs", -18.0))
+        engine.compressor_set_sidechain_highpass_enabled(int(_get(settings, "compressor_sidechain_highpass_enabled", True)))
+    limiter_enabled = _get(settings, "limiter_enabled", True)
+    engine.set_limiter_enabled(int(limiter_enabled))
+    ceiling_db = _get(settings, "limiter_ceiling_db", -0.5)
+    careful = _get(settings, "limiter_careful_output_enabled", True)
+    # effective_limiter_ceiling_db, audio/processor/control.rs:904-910, then `as f32`
+    effective = float(f32(min(ceiling_db, CAREFUL_OUTPUT_CEILING_DB) if careful else ceiling_db))
+    if limiter_enabled:
+        release_ms = _get(settings, "limiter_release_ms", 50.0)
+        engine.limiter_set_lookahead_ms(_get(settings, "limiter_lookahead_ms", 2.0))
+        engine.limiter_set_ceiling(effective)
+        engine.limiter_set_release_time(release_ms)
+        engine.true_peak_limiter_set_release_ms(float(f32(release_ms)))
+    block = int(min(max(round(sample_rate * 0.020), 1), 8192))  # python_api.rs:512-514
+    engine.set_control_block_samples(block)
+    return effective
+
+
+def _block_lengths(n: int, block: int) -> np.ndarray:
+    full, rest = divmod(n, block)
+    return np.asarray([block] * full + ([rest] if rest else []), dtype=np.int64)
+
+
+def simulate_auto_eq_chain_batch(audio: np.ndarray, sample_rate: float, bands: Sequence[tuple[float, float, float]],
+                                 settings: Mapping[str, object] | None = None, device: int = 0,
+                                 diagnostics: bool = True) -> tuple[np.ndarray, list[dict[str, Any]]]:
+    """Batched form: ``audio`` is [n_streams, n] float32; every stream uses the same preset.
+
+    Returns (output [n_streams, n] float32, one reference-shaped dict per stream).
+    """
+    started = time.perf_counter()
+    if not np.isfinite(sample_rate) or sample_rate <= 0.0:
+        raise ValueError("sample_rate must be positive and finite")
+    if len(bands) != NUM_BANDS:
+        raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    if audio.ndim != 2:
+        raise TypeError("audio must be [n_streams, n_samples]")
+    n_streams, n = audio.shape
+    engine = Engine(sample_rate, n_streams, device)
+    try:
+        effective = configure_auto_eq_chain(engine, float(sample_rate), bands, settings)
+        output = engine.process(audio) if n else audio.copy()
+        rows = engine.block_stats()
+    finally:
+        engine.close()
+    results: list[dict[str, Any]] = []
+    if diagnostics:
+        block = int(min(max(round(sample_rate * 0.020), 1), 8192))
+        lengths = _block_lengths(n, block)
+        runtime_ms = (time.perf_counter() - started) * 1000.0
+        for s in range(n_streams):
+            d = chain_diagnostics(rows[:, s], lengths, effective)
+            d["candidate_runtime_ms"] = runtime_ms
+            results.append(d)
+    return output, results
+
+
+def simulate_auto_eq_chain(audio, sample_rate: float, bands: Sequence[tuple[float, float, float]],
+                           settings: Mapping[str, object] | None = None) -> dict[str, Any]:
+    """python_api.rs:378-714 -- de-esser -> EQ -> compressor -> limiter -> true-peak limiter."""
+    started = time.perf_counter()
+    if not np.isfinite(sample_rate) or sample_rate <= 0.0:
+        raise ValueError("sample_rate must be positive and finite")
+    if len(bands) != NUM_BANDS:
+        raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
+    audio = _audio_1d(audio)
+    output, results = simulate_auto_eq_chain_batch(audio.reshape(1, -1), sample_rate, bands, settings)
+    d = results[0]
+    d["candidate_runtime_ms"] = (time.perf_counter() - started) * 1000.0
+    if _get(settings, "return_output_audio", False):
+        d["output_audio"] = output[0].tolist()  # the reference returns a Python list of floats
+    return d
+
+
+# -------------------------------------------------------------------- simulate_eq_v2
+def simulate_eq_v2(audio, sample_rate: float, bands, return_output_audio: bool = False) -> dict[str, Any]:
+    """lib.rs:214-288: typed 10-band EQ over the whole clip, peaks / true peaks / rms."""
+    arr = _bands_v2(list(bands), float(sample_rate))
+    audio = _audio_1d(audio)
+    if not np.all(np.isfinite(audio)):
+        raise ValueError("audio must contain only finite samples")
+    lib = _lib.load()
+    n = audio.size
+
+    def run(eq_enabled: bool) -> tuple[np.ndarray, np.ndarray, Engine]:
+        engine = Engine(sample_rate, 1)
+        engine.set_limiter_enabled(0)
+        engine.set_compressor_enabled(0)
+        engine.set_eq_enabled(int(eq_enabled))
+        if eq_enabled:
+            for index in range(NUM_BANDS):
+                _lib.check(lib.af_eq_set_band_config(engine._h, index, C.byref(arr[index])))
+            engine.eq_reset()
+        engine.set_control_block_samples(8192)
+        out = engine.process(audio.reshape(1, -1))[0] if n else audio.copy()
+        return out, engine.block_stats()[:, 0], engine
+
+    started = time.perf_counter()
+    output, rows, engine = run(True)
+    runtime_ms = (time.perf_counter() - started) * 1000.0
+    freqs = 20.0 * np.power(20_000.0 / 20.0, np.arange(512, dtype=np.float64) / 511.0)
+    response = np.zeros(512, dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    _lib.check(lib.af_engine_eq_magnitude_response(engine._h, freqs.ctypes.data_as(dp), 512, response.ctypes.data_as(dp)))
+    engine.close()
+    # the input true peak is the same detector over the untouched clip (lib.rs:257-260)
+    _, in_rows, probe = run(False)
+    probe.close()
+    divisor = float(max(n, 1))
+    in_sq = float(np.sum(in_rows["input_square_sum"])) if n else 0.0
+    out_sq = float(np.sum(rows["output_square_sum"])) if n else 0.0
+    result: dict[str, Any] = {
+        "input_sample_peak": float(in_rows["input_sample_peak"].max()) if n else 0.0,
+        "output_sample_peak": float(rows["output_sample_peak"].max()) if n else 0.0,
+        "input_true_peak": float(in_rows["output_true_peak"].max()) if n else 0.0,
+        "output_true_peak": float(rows["output_true_peak"].max()) if n else 0.0,
+        "input_rms": float(np.sqrt(in_sq / divisor)),
+        "output_rms": float(np.sqrt(out_sq / divisor)),
+        "max_response_db": float(response.max()),
+        "runtime_ms": runtime_ms,
+        "sample_count": int(n),
+        "algorithmic_latency_samples": 0,
+        "non_finite_output": bool(not np.all(np.isfinite(output))),
+    }
+    if return_output_audio:
+        result["output_audio"] = output.tolist()
+    return result
+
+
+# ------------------------------------------------------------- eq_magnitude_response
+def eq_magnitude_response(frequencies_hz: Sequence[float], bands: Sequence[tuple[float, float, float]],
+                          sample_rate: float) -> list[float]:
+    """lib.rs:99-150."""
+    if len(bands) != NUM_BANDS:
+        raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
+    f = np.ascontiguousarray(frequencies_hz, dtype=np.float64)
+    b = np.ascontiguousarray(np.asarray(bands, dtype=np.float64).reshape(NUM_BANDS, 3))
+    out = np.zeros_like(f)
+    dp = C.POINTER(C.c_double)
+    _lib.check(_lib.load().af_eq_magnitude_response(f.ctypes.data_as(dp), f.size, b.ctypes.data_as(dp), float(sample_rate),
+                                                     out.ctypes.data_as(dp)))
+    return out.tolist()
+
+
+def eq_magnitude_response_v2(frequencies_hz: Sequence[float], bands, sample_rate: float) -> list[float]:
+    """lib.rs:191-212."""
+    arr = _bands_v2(list(bands), float(sample_rate))
+    f = np.ascontiguousarray(frequencies_hz, dtype=np.float64)
+    out = np.zeros_like(f)
+    dp = C.POINTER(C.c_double)
+    _lib.check(_lib.load().af_eq_magnitude_response_v2(f.ctypes.data_as(dp), f.size, arr, float(sample_rate),
+                                                        out.ctypes.data_as(dp)))
+    return out.tolist()

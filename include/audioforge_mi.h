@@ -1,0 +1,199 @@
+/*
+ * audioforge_mi.h -- C ABI of the MI355X-native batched voice-DSP engine.
+ *
+ * The reference (FueledByRedBull/audio-forge, rust-core) exposes its per-frame voice
+ * chain to Python through PyO3 (`mic_eq.mic_eq_core`, rust-core/src/lib.rs:301-350);
+ * it has no C ABI of its own.  This header is the boundary a maintainer binds instead
+ * (ctypes / cffi / pyo3-ffi): an `af_engine` is N independent copies of the reference's
+ * `OfflineDspBlockProcessor` (rust-core/src/audio/processor/block_processor.rs:31-60),
+ * one per 48 kHz mono stream, resident on one GPU, driven through the same setter
+ * surface the reference's structs have.  Every entry point cites the reference method
+ * it replaces.  All functions return 0 (AF_OK) or a negative af_status; the message of
+ * the last failure on the calling thread is af_last_error().
+ *
+ * Threading: an engine is not thread safe; use one host thread per engine/device.
+ * Ownership: every buffer is caller-owned; the engine copies what it keeps.
+ */
+#ifndef AUDIOFORGE_MI_H
+#define AUDIOFORGE_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum af_status {
+  AF_OK = 0,
+  AF_ERR_INVALID_ARGUMENT = -1, /* PyValueError in the reference binding            */
+  AF_ERR_BACKEND = -2,          /* PyRuntimeError: HIP failure / no device          */
+  AF_ERR_NON_FINITE = -3,       /* "audio must contain only finite samples"         */
+  AF_ERR_STATE = -4,            /* setter used after streaming started (see below)  */
+  AF_ERR_UNSUPPORTED = -5
+} af_status;
+
+typedef struct af_engine af_engine;
+
+/* ---- stable public filter ids: rust-core/src/dsp/eq.rs:44-53 ---- */
+enum { AF_EQ_LOW_SHELF = 0, AF_EQ_BELL = 1, AF_EQ_HIGH_SHELF = 2, AF_EQ_NOTCH = 3,
+       AF_EQ_HIGH_PASS = 4, AF_EQ_LOW_PASS = 5 };
+
+/* EqBandConfig, rust-core/src/dsp/eq.rs:112-120 */
+typedef struct af_eq_band_config {
+  int32_t filter_type;
+  double frequency_hz;
+  double gain_db;
+  double q;
+  int32_t slope_db_per_octave;
+  int32_t enabled;
+} af_eq_band_config;
+
+/* OfflineDspBlockStats (block_processor.rs:1-28) + the two per-block energy sums that
+ * simulate_auto_eq_chain accumulates around each block (python_api.rs:515-553). */
+typedef struct af_block_stats {
+  float input_sample_peak;
+  float output_sample_peak;
+  float true_peak_limiter_input_peak;
+  float output_true_peak;
+  float limiter_peak_gain_reduction_db;
+  float true_peak_limiter_gain_reduction_db;
+  float compressor_gain_reduction_db;
+  float deesser_gain_reduction_db;
+  double input_square_sum;
+  double output_square_sum;
+  uint32_t true_peak_limited_events; /* 0 or 1 per block, true_peak.rs:376 */
+  uint32_t non_finite_output;
+} af_block_stats;
+
+/* layout of the audio buffers handed to af_engine_process_* */
+enum { AF_LAYOUT_STREAM_MAJOR = 0 /* [stream][time] */, AF_LAYOUT_TIME_MAJOR = 1 /* [time][stream] */ };
+
+/* kernel variants (all produce the same samples) */
+enum { AF_KERNEL_AUTO = 0, AF_KERNEL_LANE_PER_STREAM = 1, AF_KERNEL_PHASED = 2 };
+
+int af_version(void);
+const char *af_last_error(void);
+/* number of HIP devices visible; negative status when the runtime is unusable */
+int af_device_count(void);
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+/* OfflineDspBlockProcessor::new(sample_rate), block_processor.rs:46-60, for
+ * `n_streams` independent streams on HIP device `device`.  No GPU work happens until
+ * the first af_engine_process_* call (configuration is pure host work). */
+int af_engine_create(double sample_rate, int32_t n_streams, int32_t device, af_engine **out);
+void af_engine_destroy(af_engine *engine);
+/* Re-arm every stream with the configured initial state (a fresh processor with the
+ * same setter history); afterwards setters are accepted again. */
+int af_engine_reset(af_engine *engine);
+int32_t af_engine_n_streams(const af_engine *engine);
+
+/* Setters mirror the reference structs and may be called until the first
+ * af_engine_process_* call; afterwards they return AF_ERR_STATE (live retuning of
+ * resident streams is out of scope -- the reference does it through its realtime
+ * control plane, audio/processor/control.rs). */
+
+/* ---- chain switches: block_processor.rs:62-84 ----------------------------------- */
+int af_engine_set_deesser_enabled(af_engine *e, int32_t enabled);
+int af_engine_set_eq_enabled(af_engine *e, int32_t enabled);
+int af_engine_set_compressor_enabled(af_engine *e, int32_t enabled);
+int af_engine_set_limiter_enabled(af_engine *e, int32_t enabled);
+int af_engine_set_eq_before_deesser(af_engine *e, int32_t enabled);
+/* Samples per reference block: python_api.rs:512-514 uses round(0.020*fs)=960,
+ * the golden test 480 (tests.rs:1825).  Each af_engine_process_* call is cut into
+ * blocks of this size (last one short), exactly like `audio.chunks(n)`. */
+int af_engine_set_control_block_samples(af_engine *e, int32_t samples);
+/* python_api.rs:517-520: non-finite input samples become 0 (on by default) */
+int af_engine_set_input_scrub_enabled(af_engine *e, int32_t enabled);
+
+/* ---- realtime front end (off by default: the offline simulator has none) -------- */
+/* sanitize_and_clamp_input_inplace, audio/processor/routing.rs:802-823 */
+int af_engine_set_input_clamp_enabled(af_engine *e, int32_t enabled);
+/* apply_input_pre_filter: DC block + 80 Hz high-pass, routing.rs:826-843 */
+int af_engine_set_prefilter_enabled(af_engine *e, int32_t enabled, int32_t apply_fixed_highpass);
+
+/* ---- ParametricEQ: rust-core/src/dsp/eq.rs --------------------------------------- */
+int af_eq_set_band_frequency(af_engine *e, int32_t band, double frequency_hz); /* eq.rs:419-425 */
+int af_eq_set_band_gain(af_engine *e, int32_t band, double gain_db);           /* eq.rs:406-412 */
+int af_eq_set_band_q(af_engine *e, int32_t band, double q);                    /* eq.rs:432-438 */
+int af_eq_set_band_config(af_engine *e, int32_t band, const af_eq_band_config *c); /* eq.rs:468-472 */
+int af_eq_reset(af_engine *e);                                                 /* eq.rs:395-399 */
+/* EqBandConfig::validate, eq.rs:140-201; message via af_last_error() */
+int af_eq_band_config_validate(const af_eq_band_config *c, int32_t index, double sample_rate);
+
+/* ---- Compressor: rust-core/src/dsp/compressor.rs:210-371 ------------------------ */
+int af_compressor_set_threshold(af_engine *e, double threshold_db);
+int af_compressor_set_ratio(af_engine *e, double ratio);
+int af_compressor_set_attack_time(af_engine *e, double attack_ms);
+int af_compressor_set_release_time(af_engine *e, double release_ms);
+int af_compressor_set_makeup_gain(af_engine *e, double makeup_gain_db);
+int af_compressor_set_adaptive_release(af_engine *e, int32_t enabled);
+int af_compressor_set_base_release_time(af_engine *e, double release_ms);
+int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t enabled);
+int af_compressor_set_target_lufs(af_engine *e, double target_lufs);
+int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t enabled);
+
+/* ---- Limiter: rust-core/src/dsp/limiter.rs:139-184 ------------------------------ */
+int af_limiter_set_ceiling(af_engine *e, double ceiling_db);
+int af_limiter_set_release_time(af_engine *e, double release_ms);
+int af_limiter_set_lookahead_ms(af_engine *e, double lookahead_ms);
+double af_limiter_ceiling_db(const af_engine *e);
+int32_t af_limiter_lookahead_samples(const af_engine *e);
+
+/* ---- TruePeakLimiter: rust-core/src/dsp/true_peak.rs:304-313 --------------------- */
+int af_true_peak_limiter_set_release_ms(af_engine *e, float release_ms);
+
+/* ---- DeEsser: rust-core/src/dsp/deesser.rs:288-353 ------------------------------ */
+int af_deesser_set_auto_enabled(af_engine *e, int32_t enabled);
+int af_deesser_set_auto_amount(af_engine *e, double amount);
+int af_deesser_set_low_cut_hz(af_engine *e, double hz);
+int af_deesser_set_high_cut_hz(af_engine *e, double hz);
+int af_deesser_set_threshold_db(af_engine *e, double db);
+int af_deesser_set_ratio(af_engine *e, double ratio);
+int af_deesser_set_attack_ms(af_engine *e, double ms);
+int af_deesser_set_release_ms(af_engine *e, double ms);
+int af_deesser_set_max_reduction_db(af_engine *e, double db);
+
+/* ---- processing ------------------------------------------------------------------ */
+/* OfflineDspBlockProcessor::process_block_with_stats (block_processor.rs:106-161)
+ * applied to every stream, for ceil(n/control_block) consecutive blocks.
+ *
+ * _device: `in`/`out` are device pointers on the engine's device; element (s, t) is at
+ *   in[s*stream_stride + t] (stream-major) or in[t*stream_stride + s] (time-major);
+ *   `hip_stream` is a hipStream_t (NULL = default stream).  Asynchronous: returns
+ *   after enqueueing.  `in` may equal `out`.
+ * _host: host pointers; copies in, runs, copies out, synchronises. */
+int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t n_samples,
+                             int64_t stream_stride, int32_t layout, void *hip_stream);
+int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_samples,
+                           int32_t layout);
+int af_engine_synchronize(af_engine *e);
+/* Blocks produced by the last process call and their stats, row-major [block][stream]
+ * (synchronises).  `capacity` is in rows of af_block_stats. */
+int64_t af_engine_last_block_count(const af_engine *e);
+int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capacity);
+/* total samples per stream processed since create/reset */
+int64_t af_engine_samples_processed(const af_engine *e);
+/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO */
+int af_engine_set_kernel(af_engine *e, int32_t kernel);
+/* HIP-event timing of the kernels launched by the last process call, in milliseconds,
+ * measured on the stream the kernels ran on (0 when timing is disabled) */
+int af_engine_set_timing_enabled(af_engine *e, int32_t enabled);
+int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches);
+
+/* ---- stateless helpers ----------------------------------------------------------- */
+/* eq_magnitude_response, lib.rs:99-150 (legacy (freq, gain_db, q) x 10 bands) */
+int af_eq_magnitude_response(const double *frequencies_hz, size_t n, const double bands[10][3],
+                             double sample_rate, double *out_db);
+/* eq_magnitude_response_v2, lib.rs:191-212 */
+int af_eq_magnitude_response_v2(const double *frequencies_hz, size_t n,
+                                const af_eq_band_config bands[10], double sample_rate,
+                                double *out_db);
+/* engine's configured EQ, target response: ParametricEQ::magnitude_response_db, eq.rs:511-527 */
+int af_engine_eq_magnitude_response(const af_engine *e, const double *frequencies_hz, size_t n,
+                                    double *out_db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOFORGE_MI_H */

@@ -1,0 +1,261 @@
+"""GPU parity: the HIP chain (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (north_star: per-sample RMS error <= 1e-5 vs the reference):
+  * stages with no libm call on the device (prefilter, EQ, limiter, true-peak limiter/detector,
+    all index/count outputs) must be BIT-EXACT;
+  * the compressor calls log10/pow/sqrt: device libm (ocml) and glibc agree to <= 1-2 ulp of
+    f64, which can flip the last bit of an f32 output sample now and then -> max |err| <= 2e-7
+    (two ulp of f32 at 0.5 full scale) and RMS error <= 2e-8, i.e. 500x inside the budget.
+"""
+import numpy as np
+import pytest
+
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+MAX_ABS = 2e-7
+MAX_RMS = 2e-8
+
+
+@pytest.fixture(scope="module")
+def mi():
+    import mic_eq_mi
+
+    assert mic_eq_mi.CORE_AVAILABLE, "HIP library missing: GPU tests never fall back to the CPU"
+    from mic_eq_mi import _lib
+
+    assert _lib.load().af_device_count() >= 1
+    return mic_eq_mi
+
+
+def _err(a, b):
+    d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(d))) if d.size else 0.0, float(np.sqrt(np.mean(d * d))) if d.size else 0.0
+
+
+def _compare_dicts(got, want, exact_keys=(), rel=2e-5):
+    for key, ref in want.items():
+        if key in ("output_audio", "candidate_runtime_ms"):
+            continue
+        value = got[key]
+        if isinstance(ref, (bool, int, np.integer)) or key in exact_keys:
+            assert value == ref, (key, value, ref)
+        else:
+            assert abs(value - ref) <= rel * max(1.0, abs(ref)), (key, value, ref)
+
+
+def test_eq_only_is_bit_exact(mi, oracle):
+    """simulate_eq_v2 (lib.rs:214-288): default bands, a steep/edge-case layout, and a long clip."""
+    x = S.kat_signal(100)
+    layouts = [list(S.DEFAULT_TYPED_BANDS)]
+    steep = list(S.DEFAULT_TYPED_BANDS)
+    steep[0] = ("high_pass", 90.0, 0.0, 1.0, 48, True)
+    steep[3] = ("notch", 640.0, 5.0, 8.0, 12, True)
+    steep[4] = ("bell", 1000.0, 12.0, 2.0, 12, True)
+    steep[6] = ("low_shelf", 300.0, -6.0, 0.7, 12, True)
+    steep[8] = ("low_pass", 14000.0, 0.0, 1.0, 36, True)
+    steep[9] = ("high_shelf", 9000.0, 4.5, 0.9, 12, False)
+    layouts.append(steep)
+    for bands in layouts:
+        want = oracle.simulate_eq_v2(x, 48_000.0, bands, return_output_audio=True)
+        got = mi.simulate_eq_v2(x, 48_000.0, bands, return_output_audio=True)
+        assert np.array_equal(np.asarray(got["output_audio"], dtype=np.float32), want["output_audio"])
+        for key in ("input_sample_peak", "output_sample_peak", "input_true_peak", "output_true_peak", "sample_count",
+                    "non_finite_output", "algorithmic_latency_samples", "max_response_db"):
+            assert got[key] == want[key], key
+        for key in ("input_rms", "output_rms"):
+            assert abs(got[key] - want[key]) <= 1e-12 * max(1.0, want[key]), key
+
+
+def test_eq_time_domain_report_pin(mi):
+    """evaluation/eq-filter-types-report.json headroom_prediction, through the GPU path."""
+    import math
+
+    t = np.arange(96000, dtype=np.float64) / 48000.0
+    audio = (0.05 * np.sin(2.0 * np.pi * 1000.0 * t)).astype(np.float32)
+    bands = list(S.DEFAULT_TYPED_BANDS)
+    bands[4] = ("bell", 1000.0, 12.0, 2.0, 12, True)
+    r = mi.simulate_eq_v2(audio, 48_000.0, bands)
+    measured = 20.0 * math.log10(max(r["output_rms"], 1e-15) / max(r["input_rms"], 1e-15))
+    assert abs(measured - 11.996631425143294) <= 1e-11
+    assert abs(r["max_response_db"] - 11.99271646315594) <= 1e-12
+
+
+@pytest.mark.parametrize("lookahead_ms", [2.0, 1.0, 0.5])
+def test_limiter_report_fixtures(mi, oracle, lookahead_ms):
+    """The three controlled fixtures of evaluate_limiter_lookahead.py through simulate_auto_eq_chain."""
+    settings = S.limiter_settings(lookahead_ms)
+    events = 0
+    for name, x in S.limiter_cases().items():
+        want = oracle.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, settings)
+        got = mi.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, settings)
+        out = np.asarray(got["output_audio"], dtype=np.float32)
+        max_abs, rms = _err(out, want["output_audio"])
+        assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
+        _compare_dicts(got, want)
+        events += got["true_peak_limited_events"]
+    assert events == 1  # evaluation/limiter-lookahead-report.json total_true_peak_limited_events
+
+
+def test_limiter_report_waveform_pins(mi):
+    """The report's waveform-level aggregates straight from the GPU output (2 ms lookahead)."""
+    gv, te = [], []
+    for _name, x in S.limiter_cases().items():
+        r = mi.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, S.limiter_settings(2.0))
+        out = np.asarray(r["output_audio"], dtype=np.float64)
+        aligned = out[96 + 20 :]
+        ref = x[: aligned.size].astype(np.float64)
+        gv.append(S.gain_envelope_variation_db(ref, aligned))
+        te.append(S.transient_error_db(ref, aligned, S.transient_indices(ref)))
+    assert abs(float(np.median(gv)) - 1.3907917598661823) <= 1e-7
+    assert abs(float(np.median(te)) - (-44.837684744690314)) <= 1e-5
+    assert abs(float(np.percentile(te, 90.0)) - (-27.740017908805214)) <= 1e-5
+
+
+def test_limiter_and_true_peak_without_compressor_bit_exact(mi, oracle):
+    """EQ -> limiter -> TP limiter only: no device libm in the sample path -> bit exact."""
+    settings = dict(S.limiter_settings(2.0))
+    settings["compressor_enabled"] = False
+    for name, x in S.limiter_cases().items():
+        want = oracle.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, settings)
+        got = mi.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, settings)
+        assert np.array_equal(np.asarray(got["output_audio"], dtype=np.float32), want["output_audio"]), name
+        _compare_dicts(got, want, exact_keys=("true_peak_limited_events", "processed_samples"))
+
+
+def test_dynamics_aliasing_report_pins(mi, oracle):
+    want_gr = {"carrier_8k": 16.455915451049805, "carrier_11k": 16.86142921447754,
+               "carrier_15k": 16.1809024810791, "carrier_18k": 15.484599113464355}
+    for name, carrier, mod in S.ALIASING_CASES:
+        x = S.aliasing_signal(48_000, carrier, mod)
+        got = mi.simulate_auto_eq_chain(x, 48_000, S.ALIASING_BANDS, S.ALIASING_SETTINGS)
+        want = oracle.simulate_auto_eq_chain(x, 48_000, S.ALIASING_BANDS, S.ALIASING_SETTINGS)
+        assert abs(got["compressor_gain_reduction_db"] - want_gr[name]) <= 1e-5 * want_gr[name]
+        max_abs, rms = _err(got["output_audio"], want["output_audio"])
+        assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
+
+
+def test_kat_chain_without_deesser_and_adaptive_release(mi, oracle):
+    """The golden test's EQ/compressor/limiter settings (tests.rs:1795-1808) minus the de-esser,
+    480-sample blocks, legacy EQ setters (72-sample coefficient crossfade at the start)."""
+    L = oracle.lib()
+    chain = oracle.Chain(48_000.0)
+    chain.set("compressor_enabled", 1)
+    eng = mi.Engine(48_000.0, 3)
+    eng.set_compressor_enabled(1)
+    for band, (f, g, q) in {2: (180.0, -2.5, 0.8), 6: (2800.0, 3.0, 1.2), 8: (7200.0, 1.5, 1.0)}.items():
+        L.afo_eq_set_band_frequency(chain.eq, band, f); L.afo_eq_set_band_gain(chain.eq, band, g); L.afo_eq_set_band_q(chain.eq, band, q)
+        eng.eq_set_band_frequency(band, f); eng.eq_set_band_gain(band, g); eng.eq_set_band_q(band, q)
+    for name, value in (("threshold", -22.0), ("ratio", 3.5), ("attack_time", 8.0), ("release_time", 160.0), ("makeup_gain", 8.0)):
+        getattr(L, f"afo_compressor_set_{name}")(chain.compressor, value)
+        getattr(eng, f"compressor_set_{name}")(value)
+    L.afo_compressor_set_adaptive_release(chain.compressor, 1)
+    eng.compressor_set_adaptive_release(1)
+    L.afo_limiter_set_ceiling(chain.limiter, -6.0); L.afo_limiter_set_release_time(chain.limiter, 55.0)
+    eng.limiter_set_ceiling(-6.0); eng.limiter_set_release_time(55.0)
+    eng.set_control_block_samples(480)
+    x = S.kat_signal(300)
+    y = x.copy()
+    rows = []
+    for b in range(300):
+        rows.append(chain.process_block(y[b * 480 : (b + 1) * 480]))
+    batch = np.stack([x, x[::-1].copy(), x * np.float32(0.5)])
+    # two launches (state must carry across calls, including the EQ crossfade bookkeeping)
+    out_a = eng.process(batch[:, : 50 * 480 + 0])
+    st_a = eng.block_stats()
+    out_b = eng.process(batch[:, 50 * 480 :])
+    st_b = eng.block_stats()
+    out = np.concatenate([out_a, out_b], axis=1)
+    stats = np.concatenate([st_a, st_b], axis=0)
+    max_abs, rms = _err(out[0], y)
+    assert max_abs <= MAX_ABS and rms <= MAX_RMS, (max_abs, rms)
+    assert stats.shape == (300, 3)
+    comp = np.array([r.compressor_gain_reduction_db for r in rows], dtype=np.float32)
+    lim = np.array([r.limiter_peak_gain_reduction_db for r in rows], dtype=np.float32)
+    tpe = np.array([r.true_peak_limited_events for r in rows])
+    assert np.max(np.abs(stats["compressor_gain_reduction_db"][:, 0] - comp)) <= 1e-4
+    assert np.max(np.abs(stats["limiter_peak_gain_reduction_db"][:, 0] - lim)) <= 1e-4
+    assert np.array_equal(stats["true_peak_limited_events"][:, 0], tpe)
+    assert abs(float(comp.max()) - 8.687_991) <= 0.6  # same regime as the golden test (de-esser removed)
+    eng.close()
+
+
+def test_batch_streams_are_independent_and_match_oracle(mi, oracle):
+    """S3 batch (ragged: 130 streams = 2 full groups + 2 lanes), 3.3 s, default simulator settings."""
+    n_streams, n_blocks = 130, 330
+    audio = S.batch_signal(n_streams, n_blocks)
+    audio = audio[:, : n_blocks * 480 - 7]  # ragged length: last control block is short
+    settings = S.limiter_settings(2.0)
+    out, results = mi.simulate_auto_eq_chain_batch(audio, 48_000, S.LIMITER_BANDS, settings)
+    for s in (0, 1, 17, 63, 64, 127, 128, 129):
+        want = oracle.simulate_auto_eq_chain(audio[s], 48_000, S.LIMITER_BANDS, settings)
+        max_abs, rms = _err(out[s], want["output_audio"])
+        assert max_abs <= MAX_ABS and rms <= MAX_RMS, (s, max_abs, rms)
+        _compare_dicts(results[s], want)
+
+
+def test_layouts_and_inplace_give_identical_samples(mi):
+    n_streams, n = 70, 4000
+    audio = S.batch_signal(n_streams, 9)[:, :n]
+    outs = []
+    for layout in (mi.LAYOUT_STREAM_MAJOR, mi.LAYOUT_TIME_MAJOR):
+        eng = mi.Engine(48_000.0, n_streams)
+        eng.set_compressor_enabled(1)
+        eng.compressor_set_sidechain_highpass_enabled(1)
+        data = audio if layout == mi.LAYOUT_STREAM_MAJOR else np.ascontiguousarray(audio.T)
+        out = eng.process(data, layout)
+        outs.append(out if layout == mi.LAYOUT_STREAM_MAJOR else out.T)
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_prefilter_front_end_bit_exact(mi, oracle):
+    """DC block + 80 Hz high-pass (routing.rs:826-843) ahead of the chain, with NaN/clip scrubbing."""
+    import ctypes as C
+
+    L = oracle.lib()
+    x = (S.kat_signal(40) * np.float32(3.0) + np.float32(0.2)).astype(np.float32)
+    x[100] = np.nan
+    x[2000] = np.inf
+    eng = mi.Engine(48_000.0, 1)
+    eng.set_input_clamp_enabled(1)
+    eng.set_prefilter_enabled(1, 1)
+    eng.set_limiter_enabled(0)
+    eng.set_eq_enabled(0)
+    got = eng.process(x.reshape(1, -1))[0]
+    eng.close()
+
+    class Pre(C.Structure):
+        _fields_ = [("dc_x1", C.c_float), ("dc_y1", C.c_float), ("hp", C.c_byte * 256)]
+
+    pre = Pre()
+    L.afo_prefilter_init.argtypes = [C.c_void_p, C.c_double]
+    L.afo_prefilter_process_block.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int]
+    L.afo_sanitize_and_clamp.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+    L.afo_sanitize_and_clamp.restype = C.c_uint64
+    L.afo_prefilter_init(C.byref(pre), 48_000.0)
+    want = x.copy()
+    fp = want.ctypes.data_as(C.POINTER(C.c_float))
+    assert L.afo_sanitize_and_clamp(fp, want.size) > 0
+    L.afo_prefilter_process_block(C.byref(pre), fp, want.size, 1)
+    assert np.array_equal(got, want)
+
+
+def test_empty_and_tiny_inputs(mi, oracle):
+    r = mi.simulate_auto_eq_chain(np.zeros(0, dtype=np.float32), 48_000, S.LIMITER_BANDS, {"return_output_audio": True})
+    assert r["processed_samples"] == 0 and r["output_audio"] == []
+    x = S.kat_signal(1)[:5]
+    want = oracle.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, {"return_output_audio": True})
+    got = mi.simulate_auto_eq_chain(x, 48_000, S.LIMITER_BANDS, {"return_output_audio": True})
+    assert np.array_equal(np.asarray(got["output_audio"], dtype=np.float32), want["output_audio"])
+
+
+def test_setters_refused_after_streaming_started(mi):
+    eng = mi.Engine(48_000.0, 2)
+    eng.process(np.zeros((2, 64), dtype=np.float32))
+    with pytest.raises(RuntimeError):
+        eng.compressor_set_threshold(-10.0)
+    eng.reset()
+    eng.compressor_set_threshold(-10.0)
+    eng.close()
