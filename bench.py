@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the batched voice chain on MI355X (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: `--streams` independent 48 kHz mono streams x `--seconds` of audio
+through the chain (default: BASELINE.json configs[2] shape, batch 4096 x 10 s).  Rank 0
+prints ONE JSON line with BASELINE.json's metric (48 kHz mono frames/s, whole job), the
+roofline object for the dominant kernel (HIP-event timing taken inside this script on the
+stream the kernel runs on) and the CPU baseline (the KAT-pinned oracle timed on this
+host's cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "audio-forge_amd", ROOT / "tests"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALGORITHMIC_BYTES_PER_SAMPLE = 8  # 4 B f32 read + 4 B f32 write
+SAMPLE_RATE = 48_000
+
+CHAIN_SETTINGS = {  # python/tools/evaluate_limiter_lookahead.py:143-161 (BASELINE config 2 parameters)
+    "compressor_enabled": True, "compressor_threshold_db": -20.0, "compressor_ratio": 4.0,
+    "compressor_attack_ms": 10.0, "compressor_release_ms": 200.0, "compressor_makeup_gain_db": 0.0,
+    "compressor_adaptive_release": False, "compressor_auto_makeup_enabled": False,
+    "compressor_sidechain_highpass_enabled": True, "limiter_enabled": True, "limiter_ceiling_db": -0.5,
+    "limiter_release_ms": 50.0, "limiter_careful_output_enabled": True, "limiter_lookahead_ms": 2.0,
+}
+BANDS = [(80.0 * 1.75**k, 0.0, 1.0) for k in range(10)]
+
+
+def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.device) -> torch.Tensor:
+    """SURVEY.md 8(d) S3 on the GPU: per-stream reseeded golden-KAT generator, [n_streams, n] f32."""
+    from signals import KAT_NOISE_STATE, MASK64, stream_params
+
+    n = n_blocks * 480
+    a, c = 6364136223846793005, 1442695040888963407
+    mul = np.empty(n, dtype=np.uint64)
+    add = np.empty(n, dtype=np.uint64)
+    m, d = 1, 0
+    for k in range(n):  # affine powers of the LCG: state_k = mul[k]*s0 + add[k]
+        m = (m * a) & MASK64
+        d = (d * a + c) & MASK64
+        mul[k] = m
+        add[k] = d
+    mul_t = torch.from_numpy(mul.view(np.int64)).to(device)
+    add_t = torch.from_numpy(add.view(np.int64)).to(device)
+    idx = torch.arange(n, device=device, dtype=torch.float64)
+    t = idx / 48000.0
+    gate = (((torch.arange(n, device=device) // 480) // 12) % 5 == 2).to(torch.float64)
+    sib = gate * 0.35 * torch.sin(2.0 * np.pi * 7200.0 * t)
+    out = torch.empty((n_streams, n), dtype=torch.float32, device=device)
+    two_pi_t = 2.0 * np.pi * t
+    for s in range(n_streams):
+        state, f0, ph = stream_params(first_stream + s)
+        s0 = torch.tensor(np.array([state & MASK64], dtype=np.uint64).view(np.int64), device=device)
+        states = mul_t * s0 + add_t  # wrapping int64 arithmetic == uint64 LCG
+        hi = ((states >> 40) & 0xFFFFFF).to(torch.float64)
+        noise = (hi / float((1 << 24) - 1) * 2.0 - 1.0) * 0.012
+        phrase = 0.25 + 0.75 * torch.abs(torch.sin(two_pi_t * ph))
+        voiced = 0.30 * torch.sin(two_pi_t * f0) + 0.14 * torch.sin(two_pi_t * (2.0 * f0)) + 0.08 * torch.sin(two_pi_t * (15.0 * f0))
+        out[s] = (phrase * voiced + sib + noise).to(torch.float32)
+    return out
+
+
+def cpu_baseline(seconds: float, budget_s: float = 15.0) -> dict:
+    """The oracle (CPU restatement of rust-core; the Rust reference cannot be built here) on 1 host thread."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import af_oracle_py as oracle  # the checker / baseline, never the product path
+    from signals import kat_signal, stream_params
+
+    n_blocks = int(seconds * 100)
+    settings = dict(CHAIN_SETTINGS)
+    frames = 0
+    elapsed = 0.0
+    streams = 0
+    oracle.simulate_auto_eq_chain(kat_signal(20), SAMPLE_RATE, BANDS, settings)  # warm-up
+    while elapsed < budget_s and streams < 64:
+        st, f0, ph = stream_params(streams)
+        x = kat_signal(n_blocks, st, f0, ph)
+        t0 = time.perf_counter()
+        oracle.simulate_auto_eq_chain(x, SAMPLE_RATE, BANDS, settings)
+        elapsed += time.perf_counter() - t0
+        frames += x.size
+        streams += 1
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": frames / elapsed, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{streams} streams x {seconds:g} s of the same S3 workload, same chain settings, 1 thread",
+        "x_realtime": frames / elapsed / SAMPLE_RATE, "host_cpu": cpu_model, "host_cores": os.cpu_count(),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=4096, help="streams PER GPU (weak scaling)")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import mic_eq_mi
+    from mic_eq_mi import mic_eq_core as core
+
+    if not mic_eq_mi.CORE_AVAILABLE:
+        raise SystemExit("libaudioforge_mi.so is missing; run __graft_entry__.build()")
+
+    n_blocks = int(round(args.seconds * 100))
+    n = n_blocks * 480
+    streams = args.streams
+    x = synth_batch(streams, n_blocks, rank * streams, device)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+
+    engine = core.Engine(SAMPLE_RATE, streams, local_rank)
+    core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, CHAIN_SETTINGS)
+    engine.set_kernel(args.kernel)
+    engine.set_timing_enabled(1)
+    hip_stream = torch.cuda.current_stream().cuda_stream
+
+    def step() -> None:
+        engine.process_device(x.data_ptr(), y.data_ptr(), n, n, core._lib.LAYOUT_STREAM_MAJOR, hip_stream)
+
+    def barrier() -> None:
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(engine.last_kernel_ms()[0])  # waits on this step's stop event only
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # the one collective: metric reduction over ranks (RCCL over xGMI when world > 1)
+    rows = engine.block_stats()
+    metrics_sum = torch.tensor([float(rows["output_square_sum"].sum()), float(rows["input_square_sum"].sum()),
+                                float(rows["true_peak_limited_events"].sum())], dtype=torch.float64, device=device)
+    metrics_max = torch.tensor([float(rows["output_sample_peak"].max()), float(rows["output_true_peak"].max()),
+                                float(rows["compressor_gain_reduction_db"].max()), elapsed], dtype=torch.float64, device=device)
+    if distributed:
+        dist.all_reduce(metrics_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(metrics_max, op=dist.ReduceOp.MAX)
+    elapsed_max = float(metrics_max[3])
+    total_frames = world * streams * n * args.steps
+    value = total_frames / elapsed_max
+
+    if rank == 0:
+        avg_kernel_s = float(np.mean(kernel_ms)) / 1000.0
+        frames_per_launch = streams * n
+        achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        line = {
+            "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1000.0,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "x_realtime": value / SAMPLE_RATE,
+            "config": {
+                "workload": f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, 10-band EQ + compressor + 2 ms lookahead "
+                            f"limiter + 4x true-peak limiter/detector (BASELINE configs[2] shape; RNNoise stage not built yet)",
+                "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
+                "kernel": "chain_lane_kernel", "sharding": f"streams x{world}, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "chain_lane_kernel", "avg_kernel_ms": avg_kernel_s * 1000.0,
+                "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
+            },
+            "checks": {"output_rms": float(np.sqrt(float(metrics_sum[0]) / (world * streams * n))),
+                       "output_sample_peak": float(metrics_max[0]), "max_compressor_gr_db": float(metrics_max[2])},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.seconds)
+        print(json.dumps(line))
+    engine.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
