@@ -16,6 +16,10 @@
 namespace af {
 size_t lane_kernel_dynamic_lds(int lookahead_samples);
 hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipStream_t stream);
+size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples);
+hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, int variant,
+                             hipStream_t stream);
+constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
@@ -51,6 +55,7 @@ struct af_engine {
   bool started = false;
   bool params_dirty = true;
   int kernel = AF_KERNEL_AUTO;
+  int ring_variant = 0;
   bool timing = false;
   int64_t samples_processed = 0;
   int64_t last_blocks = 0;
@@ -63,6 +68,7 @@ struct af_engine {
   float *d_st32 = nullptr;
   int n_f64 = 0, n_f32 = 0;
   af::BlockStats *d_stats = nullptr;
+  int32_t *d_status = nullptr;
   int64_t stats_capacity = 0;  // rows
   float *d_io = nullptr;       // staging for the host entry point
   int64_t io_capacity = 0;     // floats
@@ -177,12 +183,24 @@ int ensure_started(af_engine *e) {
                   e->proto.limiter.lookahead_samples, af::kLdsLookaheadMax);
     export_params(e);
     if (!e->d_params) AF_HIP(hipMalloc(&e->d_params, sizeof(af::ChainParams)));
+    if (!e->d_status) {
+      AF_HIP(hipMalloc(&e->d_status, sizeof(int32_t)));
+      AF_HIP(hipMemset(e->d_status, 0, sizeof(int32_t)));
+    }
     int rc = upload_initial_state(e);
     if (rc) return rc;
     e->params_dirty = true;
     e->started = true;
     e->samples_processed = 0;
   }
+  return AF_OK;
+}
+
+int check_device_status(af_engine *e) {
+  if (!e->d_status) return AF_OK;
+  int32_t st = 0;
+  AF_HIP(hipMemcpy(&st, e->d_status, sizeof st, hipMemcpyDeviceToHost));
+  if (st != 0) return fail(AF_ERR_BACKEND, "a chain kernel abandoned a stage token (device status %d); results are invalid", st);
   return AF_OK;
 }
 
@@ -238,6 +256,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_st64);
     (void)hipFree(e->d_st32);
     (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_status);
     (void)hipFree(e->d_io);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
@@ -345,6 +364,14 @@ int af_engine_set_kernel(af_engine *e, int32_t kernel) {
   e->kernel = kernel;
   return AF_OK;
 }
+int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  const int v = waves * 100 + chunk;
+  if (v != 0 && v != 1604 && v != 1602 && v != 804 && v != 802)
+    return fail(AF_ERR_INVALID_ARGUMENT, "no token-ring kernel is built for %d waves x %d-sample chunks", waves, chunk);
+  e->ring_variant = v;
+  return AF_OK;
+}
 int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
   e->timing = on != 0;
@@ -392,6 +419,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   a.in = in;
   a.out = out;
   a.stats = e->d_stats;
+  a.status = e->d_status;
   a.n_samples = n_samples;
   a.stream_stride = stream_stride;
   a.samples_before = e->samples_processed;
@@ -404,7 +432,21 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     AF_HIP(hipEventRecord(e->ev_start, stream));
   }
-  AF_HIP(af::launch_chain_lane(a, e->host_params.lim.lookahead_samples, stream));
+  const bool ring_fits = af::ring_kernel_dynamic_lds(e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples) <=
+                         af::kMaxLdsBytes;
+  int kernel = e->kernel;
+  if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
+  if (kernel == AF_KERNEL_PHASED && !ring_fits)
+    return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
+  if (kernel == AF_KERNEL_PHASED) {
+    // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
+    AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
+    if (e->timing) AF_HIP(hipEventRecord(e->ev_start, stream));
+    AF_HIP(af::launch_chain_ring(a, e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples, e->ring_variant,
+                                 stream));
+  } else {
+    AF_HIP(af::launch_chain_lane(a, e->host_params.lim.lookahead_samples, stream));
+  }
   e->last_launches = 1;
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
@@ -428,7 +470,7 @@ int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_
   if (int rc = af_engine_process_device(e, e->d_io, e->d_io, n_samples, stride, layout, nullptr)) return rc;
   AF_HIP(hipStreamSynchronize(nullptr));
   if (total > 0) AF_HIP(hipMemcpy(out, e->d_io, sizeof(float) * total, hipMemcpyDeviceToHost));
-  return AF_OK;
+  return check_device_status(e);
 }
 
 int af_engine_synchronize(af_engine *e) {
@@ -436,7 +478,7 @@ int af_engine_synchronize(af_engine *e) {
   if (!e->started) return AF_OK;
   AF_HIP(hipSetDevice(e->device));
   AF_HIP(hipStreamSynchronize(e->last_stream));
-  return AF_OK;
+  return check_device_status(e);
 }
 
 int64_t af_engine_last_block_count(const af_engine *e) { return e ? e->last_blocks : 0; }
@@ -450,7 +492,7 @@ int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capaci
   AF_HIP(hipSetDevice(e->device));
   AF_HIP(hipStreamSynchronize(e->last_stream));
   AF_HIP(hipMemcpy(out, e->d_stats, sizeof(af::BlockStats) * rows, hipMemcpyDeviceToHost));
-  return AF_OK;
+  return check_device_status(e);
 }
 
 int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches) {

@@ -144,6 +144,7 @@ struct LaunchArgs {
   const float *in;
   float *out;
   BlockStats *stats;          // [blocks][n_streams]
+  int32_t *status;            // device word: non-zero when a kernel gave up on a token (never expected)
   int64_t n_samples;
   int64_t stream_stride;
   int64_t samples_before;     // samples processed by earlier launches (van-Herk phase)

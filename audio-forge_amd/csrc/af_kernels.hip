@@ -15,28 +15,9 @@
 // audio/processor/{routing,block_processor}.rs; line numbers are cited per function.
 #include <hip/hip_runtime.h>
 
-#include "af_device.h"
-#include "tp_fir_table.h"
+#include "af_dsp.h"
 
 namespace af {
-
-// ------------------------------------------------------------------ small helpers
-__device__ __forceinline__ double dclamp(double x, double lo, double hi) {
-  return x < lo ? lo : (x > hi ? hi : x);
-}
-__device__ __forceinline__ float fclamp(float x, float lo, float hi) {
-  return x < lo ? lo : (x > hi ? hi : x);
-}
-// dsp/util.rs:18-20
-__device__ __forceinline__ double lin2db(double linear, double floor_) {
-  return 20.0 * log10(fmax(fabs(linear), floor_));
-}
-// dsp/util.rs:12-14
-__device__ __forceinline__ double db2lin(double db) { return pow(10.0, db / 20.0); }
-
-__device__ __forceinline__ bool finite_f32(float v) {
-  return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
-}
 
 struct TileLds {
   float x[kTile][kLanes + 1];            // working tile; +1 column: conflict-free transposed fill
@@ -126,22 +107,6 @@ struct CompState {
   double peak_env_db, rms_env_sq, gr, fast_env, slow_env, cur_release_ms, target_release_ms;
   double release_coeff, smoothed_makeup;
 };
-
-// Compressor::compute_gain_reduction, dsp/compressor.rs:657-678
-__device__ __forceinline__ double comp_gain_reduction(const CompressorParams &p, double detector_db) {
-  const double comp_factor = 1.0 - 1.0 / p.ratio;
-  if (p.knee_db <= 0.0) {
-    if (detector_db <= p.threshold_db) return 0.0;
-    return (detector_db - p.threshold_db) * comp_factor;
-  }
-  const double knee_half = p.knee_db / 2.0;
-  const double knee_start = p.threshold_db - knee_half;
-  const double knee_end = p.threshold_db + knee_half;
-  if (detector_db <= knee_start) return 0.0;
-  if (detector_db >= knee_end) return (detector_db - p.threshold_db) * comp_factor;
-  const double x = detector_db - knee_start;
-  return comp_factor * x * x / (2.0 * p.knee_db);
-}
 
 // Compressor::process_sample_impl(update_makeup_gain = false), dsp/compressor.rs:725-774
 __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompState &s, float input,

@@ -110,6 +110,7 @@ SIGNATURES = {
     "af_engine_read_block_stats": (C.c_int, [_vp, C.POINTER(BlockStats), _i64]),
     "af_engine_samples_processed": (_i64, [_vp]),
     "af_engine_set_kernel": (C.c_int, [_vp, _i32]),
+    "af_engine_set_ring_variant": (C.c_int, [_vp, _i32, _i32]),
     "af_engine_set_timing_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(_i32)]),
     "af_eq_magnitude_response": (C.c_int, [_dp, _sz, _dp, _d, _dp]),

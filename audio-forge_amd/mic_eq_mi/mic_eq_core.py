@@ -55,9 +55,22 @@ class Engine:
         handle = C.c_void_p()
         _lib.check(self._lib.af_engine_create(float(sample_rate), int(n_streams), int(device), C.byref(handle)))
         self._h = handle
+        self._apply_variant_override()
         self.sample_rate = float(sample_rate)
         self.n_streams = int(n_streams)
         self.device = int(device)
+
+    def _apply_variant_override(self) -> None:
+        """AF_KERNEL_VARIANT=lane | ring-<waves>x<chunk> pins the kernel (tests and tuning runs)."""
+        import os
+
+        variant = os.environ.get("AF_KERNEL_VARIANT", "")
+        if variant == "lane":
+            _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_LANE_PER_STREAM))
+        elif variant.startswith("ring-"):
+            waves, chunk = (int(v) for v in variant[5:].split("x"))
+            _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_PHASED))
+            _lib.check(self._lib.af_engine_set_ring_variant(self._h, waves, chunk))
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -120,6 +120,7 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=4096, help="streams PER GPU (weak scaling)")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--variant", type=str, default="", help="lane | ring-<waves>x<chunk> (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,6 +140,8 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.variant:
+        os.environ["AF_KERNEL_VARIANT"] = args.variant
     import mic_eq_mi
     from mic_eq_mi import mic_eq_core as core
 
@@ -154,7 +157,8 @@ def main() -> None:
 
     engine = core.Engine(SAMPLE_RATE, streams, local_rank)
     core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, CHAIN_SETTINGS)
-    engine.set_kernel(args.kernel)
+    if not args.variant:
+        engine.set_kernel(args.kernel)
     engine.set_timing_enabled(1)
     hip_stream = torch.cuda.current_stream().cuda_stream
 

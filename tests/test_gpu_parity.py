@@ -18,9 +18,14 @@ MAX_ABS = 2e-7
 MAX_RMS = 2e-8
 
 
-@pytest.fixture(scope="module")
-def mi():
+@pytest.fixture(scope="module", params=["ring-8x4", "ring-16x4", "ring-16x2", "lane"])
+def mi(request):
+    """Every test runs once per kernel variant (selected through AF_KERNEL_VARIANT)."""
+    import os
+
     import mic_eq_mi
+
+    os.environ["AF_KERNEL_VARIANT"] = request.param
 
     assert mic_eq_mi.CORE_AVAILABLE, "HIP library missing: GPU tests never fall back to the CPU"
     from mic_eq_mi import _lib
