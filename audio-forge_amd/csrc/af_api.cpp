@@ -367,7 +367,7 @@ int af_engine_set_kernel(af_engine *e, int32_t kernel) {
 int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
   const int v = waves * 100 + chunk;
-  if (v != 0 && v != 1604 && v != 1602 && v != 804 && v != 802)
+  if (v != 0 && v != 1604 && v != 1602 && v != 804 && v != 802 && v != 1204 && v != 1202)
     return fail(AF_ERR_INVALID_ARGUMENT, "no token-ring kernel is built for %d waves x %d-sample chunks", waves, chunk);
   e->ring_variant = v;
   return AF_OK;

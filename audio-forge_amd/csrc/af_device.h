@@ -47,6 +47,8 @@ struct CompressorParams {
   double makeup_gain_db, makeup_smoothing_coeff, makeup_silence_relax_coeff;
   double speech_activity_smoothing_coeff, target_lufs, noise_reference_reliability;
   double sample_rate;
+  // host-evaluated pieces of compute_gain_reduction (compressor.rs:657-678); same IEEE ops, done once
+  double comp_factor, knee_start, knee_end, two_knee, two_knee_recip;
   int32_t adaptive_release, sidechain_highpass_enabled, auto_makeup_enabled, pad;
 };
 

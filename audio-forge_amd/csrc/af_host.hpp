@@ -372,6 +372,11 @@ struct CompressorProto {
     p.speech_activity_smoothing_coeff = speech_activity_smoothing_coeff;
     p.target_lufs = target_lufs; p.noise_reference_reliability = noise_reference_reliability;
     p.sample_rate = sample_rate;
+    p.comp_factor = 1.0 - 1.0 / ratio;
+    p.knee_start = threshold_db - knee_db / 2.0;
+    p.knee_end = threshold_db + knee_db / 2.0;
+    p.two_knee = 2.0 * knee_db;
+    p.two_knee_recip = knee_db > 0.0 ? 1.0 / (2.0 * knee_db) : 0.0;
     p.adaptive_release = adaptive_release; p.sidechain_highpass_enabled = sidechain_highpass_enabled;
     p.auto_makeup_enabled = auto_makeup_enabled;
     return p;

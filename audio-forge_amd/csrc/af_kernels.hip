@@ -131,7 +131,7 @@ __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompStat
     const double voiced_rms = fmax(sqrt(s.voiced_env), 1e-8);
     const double presence_rms = sqrt(s.presence_env);
     s.plosive = dclamp(low_rms / voiced_rms, 0.0, 32.0);
-    const double plosive_amount = dclamp((s.plosive - 1.25) / (5.0 - 1.25), 0.0, 1.0);
+    const double plosive_amount = dclamp(div_known(s.plosive - 1.25, 3.75, 1.0 / 3.75), 0.0, 1.0);
     const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
     const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
     const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
@@ -157,8 +157,8 @@ __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompStat
   // current_release_ms never moves off base_release_ms, so the host-computed value is exact;
   // in adaptive mode the per-sample exp() result is dead and is refreshed at launch end.
   if (p.adaptive_release) {
-    const double sustained = dclamp(s.slow_env / (3.0 + 3.0), 0.0, 1.0);
-    const double transient_bias = dclamp((s.fast_env - s.slow_env) / (3.0 + 4.0), 0.0, 1.0);
+    const double sustained = dclamp(div_known(s.slow_env, 6.0, 1.0 / 6.0), 0.0, 1.0);
+    const double transient_bias = dclamp(div_known(s.fast_env - s.slow_env, 7.0, 1.0 / 7.0), 0.0, 1.0);
     const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
     s.target_release_ms = 50.0 + syllabic * (400.0 - 50.0);
   } else {

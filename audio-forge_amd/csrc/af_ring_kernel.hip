@@ -21,6 +21,8 @@
 // in steady state the waves stagger themselves and nobody waits.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "af_dsp.h"
 
 namespace af {
@@ -78,10 +80,10 @@ __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
 }
 
 // Bandlimited4xPeak::observe (true_peak.rs:173-186) over a shared ring: sample n sits in row n & 127
-__device__ __forceinline__ float tp_observe_ring(const float *ring, int64_t n, int lane) {
+__device__ __forceinline__ float tp_observe_ring(const float *ring, int n, int lane) {
   float h[kTpTaps];
 #pragma unroll
-  for (int k = 0; k < kTpTaps; ++k) h[k] = ring[(size_t)((n - k) & (kTpRing - 1)) * kLanes + lane];
+  for (int k = 0; k < kTpTaps; ++k) h[k] = ring[((n - k) & (kTpRing - 1)) * kLanes + lane];
   float peak = fabsf(h[0]);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   double *l64 = reinterpret_cast<double *>(lds_raw + 256);
   const int rows64 = kR64Eq + 4 * P.n_eq_sections;
   float *l32 = reinterpret_cast<float *>(lds_raw + 256 + (size_t)rows64 * kLanes * sizeof(double));
-#define L64(row) l64[(size_t)(row)*kLanes + lane]
-#define L32(row) l32[(size_t)(row)*kLanes + lane]
+#define L64(row) l64[(row)*kLanes + lane]
+#define L32(row) l32[(row)*kLanes + lane]
 
   const int tid = threadIdx.x;
   const int lane = tid & (kLanes - 1);
@@ -181,457 +183,463 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
     const bool last_in_block = i * kChunk + len == blk_len;
     BlockStats *row = a.stats ? &a.stats[b * NS + sc] : nullptr;
 
-    // ---- load the chunk (issued before the first token wait)
-    float x[kChunk];
-    if (vec_ok && len == kChunk) {
-      const float *src = &a.in[(int64_t)s * a.stream_stride + t0];
-      if constexpr (kChunk == 2) {
-        const float2 v = valid ? *reinterpret_cast<const float2 *>(src) : make_float2(0, 0);
-        x[0] = v.x; x[1] = v.y;
-      } else {
-#pragma unroll
-        for (int k4 = 0; k4 < kChunk; k4 += 4) {
-          const float4 v = valid ? *reinterpret_cast<const float4 *>(src + k4) : make_float4(0, 0, 0, 0);
-          x[k4] = v.x; x[k4 + 1] = v.y; x[k4 + 2] = v.z; x[k4 + 3] = v.w;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k) {
-        x[k] = 0.0f;
-        if (valid && k < len)
-          x[k] = a.layout == 0 ? a.in[(int64_t)s * a.stream_stride + t0 + k] : a.in[(t0 + k) * a.stream_stride + s];
-      }
-    }
-
-    // =========================== token: input scrub, block input stats, DC block + fixed HP
-    token_wait(turn, kTokIn, q);
-    {
-      double in_sq = first_in_block ? 0.0 : L64(kR64InSq);
-      float in_peak = first_in_block ? 0.0f : L32(kR32InPeak);
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) {
-          float v = x[k];
-          if ((flags & (kFlagInputScrub | kFlagInputClamp)) && !finite_f32(v)) v = 0.0f;
-          if (flags & kFlagInputClamp) v = fclamp(v, -1.0f, 1.0f);
-          x[k] = v;
-          in_sq += (double)v * (double)v;
-          in_peak = fmaxf(in_peak, fabsf(v));
-        }
-      L64(kR64InSq) = in_sq;
-      L32(kR32InPeak) = in_peak;
-      if (last_in_block && valid && row) {
-        row->input_square_sum = in_sq;
-        row->input_sample_peak = in_peak;
-      }
-      if (flags & kFlagDcBlock) {  // routing.rs:826-843
-        float dc_x1 = L32(kR32DcX1), dc_y1 = L32(kR32DcY1);
-        double z1 = L64(kR64PreZ1), z2 = L64(kR64PreZ2);
-        const BiquadCoef c = P.pre_hp;
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k)
-          if (k < len) {
-            const float in = x[k];
-            const float o = in - dc_x1 + 0.995f * dc_y1;
-            dc_x1 = in;
-            dc_y1 = o;
-            float r = o;
-            if (flags & kFlagPreHighpass) {
-              const double xin = (double)o;
-              const double y = c.b0 * xin + z1;
-              z1 = c.b1 * xin - c.a1 * y + z2;
-              z2 = c.b2 * xin - c.a2 * y;
-              r = (float)y;
-            }
-            x[k] = r;
+    const int nb = (int)((n0 + t0) & (kTpRing - 1));  // ring row of the chunk's first sample
+    auto chunk_body = [&](auto full_tag) {
+      constexpr bool kFull = decltype(full_tag)::value;  // a full chunk needs no per-sample guards
+      // ---- load the chunk (issued before the first token wait)
+      float x[kChunk];
+      if (vec_ok && kFull) {
+        const float *src = &a.in[(int64_t)s * a.stream_stride + t0];
+        if constexpr (kChunk == 2) {
+          const float2 v = valid ? *reinterpret_cast<const float2 *>(src) : make_float2(0, 0);
+          x[0] = v.x; x[1] = v.y;
+        } else {
+  #pragma unroll
+          for (int k4 = 0; k4 < kChunk; k4 += 4) {
+            const float4 v = valid ? *reinterpret_cast<const float4 *>(src + k4) : make_float4(0, 0, 0, 0);
+            x[k4] = v.x; x[k4 + 1] = v.y; x[k4 + 2] = v.z; x[k4 + 3] = v.w;
           }
-        L32(kR32DcX1) = dc_x1;
-        L32(kR32DcY1) = dc_y1;
-        L64(kR64PreZ1) = z1;
-        L64(kR64PreZ2) = z2;
+        }
+      } else {
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+          x[k] = 0.0f;
+          if (valid && (kFull || k < len))
+            x[k] = a.layout == 0 ? a.in[(int64_t)s * a.stream_stride + t0 + k] : a.in[(t0 + k) * a.stream_stride + s];
+        }
       }
-    }
-    token_pass(turn, kTokIn, q);
 
-    // =========================== tokens: EQ section groups (eq.rs:371-379, biquad.rs:263-327)
-    for (int g = 0; g < n_groups; ++g) {
-      const int k0 = g * kEqGroup;
-      const int k1 = (k0 + kEqGroup) < nsec ? (k0 + kEqGroup) : nsec;
-      token_wait(turn, kTokEq0 + g, q);
-      for (int ks = k0; ks < k1; ++ks) {
-        const SectionParams &sp = P.eq[ks];
-        double z1 = L64(kR64Eq + 4 * ks), z2 = L64(kR64Eq + 4 * ks + 1);
-        BiquadCoef c = sp.active;
-        int rem = sp.xf_remaining - (int)(t0 < sp.xf_remaining ? t0 : sp.xf_remaining);
-        if (rem > 0) {
-          const BiquadCoef p = sp.pending;
-          double pz1 = L64(kR64Eq + 4 * ks + 2), pz2 = L64(kR64Eq + 4 * ks + 3);
-          const double total = (double)sp.xf_total;
-#pragma unroll
+      // =========================== token: input scrub, block input stats, DC block + fixed HP
+      token_wait(turn, kTokIn, q);
+      {
+        double in_sq = first_in_block ? 0.0 : L64(kR64InSq);
+        float in_peak = first_in_block ? 0.0f : L32(kR32InPeak);
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) {
+            float v = x[k];
+            if ((flags & (kFlagInputScrub | kFlagInputClamp)) && !finite_f32(v)) v = 0.0f;
+            if (flags & kFlagInputClamp) v = fclamp(v, -1.0f, 1.0f);
+            x[k] = v;
+            in_sq += (double)v * (double)v;
+            in_peak = fmaxf(in_peak, fabsf(v));
+          }
+        L64(kR64InSq) = in_sq;
+        L32(kR32InPeak) = in_peak;
+        if (last_in_block && valid && row) {
+          row->input_square_sum = in_sq;
+          row->input_sample_peak = in_peak;
+        }
+        if (flags & kFlagDcBlock) {  // routing.rs:826-843
+          float dc_x1 = L32(kR32DcX1), dc_y1 = L32(kR32DcY1);
+          double z1 = L64(kR64PreZ1), z2 = L64(kR64PreZ2);
+          const BiquadCoef c = P.pre_hp;
+  #pragma unroll
           for (int k = 0; k < kChunk; ++k)
-            if (k < len) {
-              const double in = (double)x[k];
-              const double ya = c.b0 * in + z1;
-              z1 = c.b1 * in - c.a1 * ya + z2;
-              z2 = c.b2 * in - c.a2 * ya;
-              double y = ya;
-              if (rem > 0) {
-                const double yp = p.b0 * in + pz1;
-                pz1 = p.b1 * in - p.a1 * yp + pz2;
-                pz2 = p.b2 * in - p.a2 * yp;
-                const double fade = (double)(sp.xf_total - rem + 1) / total;
-                y = ya * (1.0 - fade) + yp * fade;
-                rem -= 1;
-                if (rem == 0) {
-                  c = p;
-                  z1 = pz1;
-                  z2 = pz2;
+            if (kFull || k < len) {
+              const float in = x[k];
+              const float o = in - dc_x1 + 0.995f * dc_y1;
+              dc_x1 = in;
+              dc_y1 = o;
+              float r = o;
+              if (flags & kFlagPreHighpass) {
+                const double xin = (double)o;
+                const double y = c.b0 * xin + z1;
+                z1 = c.b1 * xin - c.a1 * y + z2;
+                z2 = c.b2 * xin - c.a2 * y;
+                r = (float)y;
+              }
+              x[k] = r;
+            }
+          L32(kR32DcX1) = dc_x1;
+          L32(kR32DcY1) = dc_y1;
+          L64(kR64PreZ1) = z1;
+          L64(kR64PreZ2) = z2;
+        }
+      }
+      token_pass(turn, kTokIn, q);
+
+      // =========================== tokens: EQ section groups (eq.rs:371-379, biquad.rs:263-327)
+      for (int g = 0; g < n_groups; ++g) {
+        const int k0 = g * kEqGroup;
+        const int k1 = (k0 + kEqGroup) < nsec ? (k0 + kEqGroup) : nsec;
+        token_wait(turn, kTokEq0 + g, q);
+        for (int ks = k0; ks < k1; ++ks) {
+          const SectionParams &sp = P.eq[ks];
+          double z1 = L64(kR64Eq + 4 * ks), z2 = L64(kR64Eq + 4 * ks + 1);
+          BiquadCoef c = sp.active;
+          int rem = sp.xf_remaining - (int)(t0 < sp.xf_remaining ? t0 : sp.xf_remaining);
+          if (rem > 0) {
+            const BiquadCoef p = sp.pending;
+            double pz1 = L64(kR64Eq + 4 * ks + 2), pz2 = L64(kR64Eq + 4 * ks + 3);
+            const double total = (double)sp.xf_total;
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) {
+                const double in = (double)x[k];
+                const double ya = c.b0 * in + z1;
+                z1 = c.b1 * in - c.a1 * ya + z2;
+                z2 = c.b2 * in - c.a2 * ya;
+                double y = ya;
+                if (rem > 0) {
+                  const double yp = p.b0 * in + pz1;
+                  pz1 = p.b1 * in - p.a1 * yp + pz2;
+                  pz2 = p.b2 * in - p.a2 * yp;
+                  const double fade = (double)(sp.xf_total - rem + 1) / total;
+                  y = ya * (1.0 - fade) + yp * fade;
+                  rem -= 1;
+                  if (rem == 0) {
+                    c = p;
+                    z1 = pz1;
+                    z2 = pz2;
+                  }
+                }
+                x[k] = (float)y;
+              }
+            L64(kR64Eq + 4 * ks + 2) = pz1;
+            L64(kR64Eq + 4 * ks + 3) = pz2;
+          } else {
+            if (sp.xf_remaining > 0) c = sp.pending;
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) {
+                const double in = (double)x[k];
+                const double y = c.b0 * in + z1;
+                z1 = c.b1 * in - c.a1 * y + z2;
+                z2 = c.b2 * in - c.a2 * y;
+                x[k] = (float)y;
+              }
+          }
+          L64(kR64Eq + 4 * ks) = z1;
+          L64(kR64Eq + 4 * ks + 1) = z2;
+        }
+        token_pass(turn, kTokEq0 + g, q);
+      }
+
+      // =========================== compressor (compressor.rs:700-774)
+      if (flags & kFlagCompressor) {
+        const CompressorParams &cp = P.comp;
+        double d[kChunk], inst_peak_db[kChunk], rms_db[kChunk], weight_db[kChunk];
+        double low_e[kChunk], voiced_e[kChunk], presence_e[kChunk], rms_e[kChunk];
+        // ---- token A: side-chain high-pass + band / rms envelopes (linear recurrences)
+        token_wait(turn, kTokCompA, q);
+        {
+          double rms_env = L64(kR64RmsEnvSq);
+          if (cp.sidechain_highpass_enabled) {
+            double prev_in = L64(kR64ScPrevIn), prev_out = L64(kR64ScPrevOut);
+            double low_env = L64(kR64LowEnv), voiced_env = L64(kR64VoicedEnv), presence_env = L64(kR64PresenceEnv);
+            const double kk = cp.band_env_coeff;
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) {
+                const double xin = (double)x[k];
+                const double dd = cp.sidechain_highpass_coeff * (prev_out + xin - prev_in);
+                prev_in = xin;
+                prev_out = dd;
+                const double low = xin - dd;
+                const double presence = 0.65 * dd + 0.35 * (dd - low);
+                low_env = kk * low_env + (1.0 - kk) * low * low;
+                voiced_env = kk * voiced_env + (1.0 - kk) * dd * dd;
+                presence_env = kk * presence_env + (1.0 - kk) * presence * presence;
+                rms_env = cp.rms_coeff * rms_env + (1.0 - cp.rms_coeff) * (dd * dd);
+                d[k] = dd;
+                low_e[k] = low_env;
+                voiced_e[k] = voiced_env;
+                presence_e[k] = presence_env;
+                rms_e[k] = rms_env;
+              }
+            L64(kR64ScPrevIn) = prev_in;
+            L64(kR64ScPrevOut) = prev_out;
+            L64(kR64LowEnv) = low_env;
+            L64(kR64VoicedEnv) = voiced_env;
+            L64(kR64PresenceEnv) = presence_env;
+          } else {
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) {
+                const double dd = (double)x[k];
+                rms_env = cp.rms_coeff * rms_env + (1.0 - cp.rms_coeff) * (dd * dd);
+                d[k] = dd;
+                rms_e[k] = rms_env;
+              }
+          }
+          L64(kR64RmsEnvSq) = rms_env;
+        }
+        token_pass(turn, kTokCompA, q);
+        // ---- feed-forward: detector weight, instantaneous peak and RMS levels in dB
+        double plosive_last = 0.0;
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) {
+            weight_db[k] = 0.0;
+            if (cp.sidechain_highpass_enabled) {  // update_sidechain_band_metrics, compressor.rs:438-449
+              const double low_rms = sqrt(low_e[k]);
+              const double voiced_rms = fmax(sqrt(voiced_e[k]), 1e-8);
+              const double presence_rms = sqrt(presence_e[k]);
+              const double plosive = dclamp(low_rms / voiced_rms, 0.0, 32.0);
+              plosive_last = plosive;
+              const double plosive_amount = dclamp(div_known(plosive - 1.25, 3.75, 1.0 / 3.75), 0.0, 1.0);
+              const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
+              const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
+              const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
+              weight_db[k] = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
+            }
+            inst_peak_db[k] = lin2db(fabs(d[k]), 1e-10);
+            rms_db[k] = lin2db(sqrt(rms_e[k]), 1e-10);
+          }
+        // ---- token C: log-domain peak envelope (compressor.rs:735-742)
+        double peak_db[kChunk];
+        token_wait(turn, kTokCompC, q);
+        {
+          double pe = L64(kR64PeakEnvDb);
+  #pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) {
+              const double pk = inst_peak_db[k] > pe ? cp.attack_coeff : cp.detector_release_coeff;
+              pe = pk * pe + (1.0 - pk) * inst_peak_db[k];
+              peak_db[k] = pe;
+            }
+          L64(kR64PeakEnvDb) = pe;
+          if (len > 0) L64(kR64Plosive) = plosive_last;  // diagnostic state only (compressor.rs:441)
+        }
+        token_pass(turn, kTokCompC, q);
+        // ---- feed-forward: blended detector level -> static gain-reduction target
+        double target[kChunk];
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) {
+            const double blended = 0.6 * db2lin(peak_db[k]) + 0.4 * db2lin(rms_db[k]);
+            target[k] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_db[k]);
+          }
+        // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
+        double gr_k[kChunk];
+        double makeup_lin;
+        token_wait(turn, kTokCompE, q);
+        {
+          double gr = L64(kR64Gr), fast = L64(kR64FastEnv), slow = L64(kR64SlowEnv);
+          double cur_ms = L64(kR64CurReleaseMs), tgt_ms = L64(kR64TargetReleaseMs);
+          const double rel_coeff = L64(kR64ReleaseCoeff);
+          makeup_lin = L64(kR64MakeupLin);
+  #pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) {
+              if (cp.adaptive_release) {
+                const double sustained = dclamp(div_known(slow, 6.0, 1.0 / 6.0), 0.0, 1.0);
+                const double transient_bias = dclamp(div_known(fast - slow, 7.0, 1.0 / 7.0), 0.0, 1.0);
+                const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
+                tgt_ms = 50.0 + syllabic * (400.0 - 50.0);
+              } else {
+                tgt_ms = cp.base_release_ms;
+              }
+              if (fabs(tgt_ms - cur_ms) > 1.0) {
+                cur_ms = cp.release_smoothing_coeff * cur_ms + (1.0 - cp.release_smoothing_coeff) * tgt_ms;
+              } else {
+                cur_ms = tgt_ms;
+              }
+              const double tg = target[k];
+              if (!cp.adaptive_release) {
+                const double kk = tg > gr ? cp.attack_coeff : rel_coeff;
+                gr = kk * gr + (1.0 - kk) * tg;
+                fast = gr;
+                slow = 0.0;
+              } else {
+                if (tg > gr) {
+                  fast = cp.attack_coeff * gr + (1.0 - cp.attack_coeff) * tg;
+                } else {
+                  fast = cp.fast_release_coeff * fast + (1.0 - cp.fast_release_coeff) * tg;
+                }
+                if (tg > 3.0) {
+                  slow = cp.slow_charge_coeff * slow + (1.0 - cp.slow_charge_coeff) * tg;
+                } else {
+                  slow *= cp.slow_release_coeff;
+                }
+                gr = fmax(fast, slow);
+              }
+              gr_k[k] = gr;
+            }
+          L64(kR64Gr) = gr;
+          L64(kR64FastEnv) = fast;
+          L64(kR64SlowEnv) = slow;
+          L64(kR64CurReleaseMs) = cur_ms;
+          L64(kR64TargetReleaseMs) = tgt_ms;
+          if (last_in_block) {  // update_auto_makeup_gain with auto-makeup off (compressor.rs:604-617)
+            double sm = L64(kR64SmoothedMakeup);
+            const double makeup_coeff = pow(cp.makeup_smoothing_coeff, (double)(blk_len < 1 ? 1 : blk_len));
+            const double tgt = cp.makeup_gain_db;
+            if (fabs(tgt - sm) > 0.1) {
+              sm = makeup_coeff * sm + (1.0 - makeup_coeff) * tgt;
+            } else {
+              sm = tgt;
+            }
+            L64(kR64SmoothedMakeup) = sm;
+            L64(kR64MakeupLin) = db2lin(sm);
+            if (valid && row) row->compressor_gr_db = (float)gr;
+          }
+        }
+        token_pass(turn, kTokCompE, q);
+        // ---- feed-forward: apply gain (compressor.rs:771-773)
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) x[k] = (float)((double)x[k] * (db2lin(-gr_k[k]) * makeup_lin));
+      }
+
+      // =========================== limiter + true-peak limiter
+      float itp[kChunk];
+      if (flags & kFlagLimiter) {
+        const double ceil_lin = P.lim.ceiling_linear;
+        const double rc = P.lim.release_coeff;
+        float *ring = &l32[kR32LimRing * kLanes];
+        float *suf = &l32[(kR32LimRing + W) * kLanes];
+        // ---- token: lookahead limiter (limiter.rs:246-284), sliding max by block prefix/suffix maxima
+        token_wait(turn, kTokLim, q);
+        {
+          double g = L64(kR64LimGain);
+          double gmin = first_in_block ? 1.0 : L64(kR64LimGmin);
+          float prefix = L32(kR32LimPrefix);
+          int j = (int)((n0 + t0) % W);
+  #pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) {
+              const float xin = x[k];
+              const float ax = fabsf(xin);
+              const int jn = (j + 1 == W) ? 0 : j + 1;
+              const float delayed = ring[jn * kLanes + lane];
+              const float sfx = (j + 1 < W) ? suf[(j + 1) * kLanes + lane] : 0.0f;
+              prefix = (j == 0) ? ax : fmaxf(prefix, ax);
+              const double peak = (double)fmaxf(sfx, prefix);
+              ring[j * kLanes + lane] = xin;
+              if (j + 1 == W) {
+                float m = 0.0f;
+                for (int kk = W - 1; kk >= 0; --kk) {
+                  m = fmaxf(m, fabsf(ring[kk * kLanes + lane]));
+                  suf[kk * kLanes + lane] = m;
                 }
               }
-              x[k] = (float)y;
-            }
-          L64(kR64Eq + 4 * ks + 2) = pz1;
-          L64(kR64Eq + 4 * ks + 3) = pz2;
-        } else {
-          if (sp.xf_remaining > 0) c = sp.pending;
-#pragma unroll
-          for (int k = 0; k < kChunk; ++k)
-            if (k < len) {
-              const double in = (double)x[k];
-              const double y = c.b0 * in + z1;
-              z1 = c.b1 * in - c.a1 * y + z2;
-              z2 = c.b2 * in - c.a2 * y;
-              x[k] = (float)y;
-            }
-        }
-        L64(kR64Eq + 4 * ks) = z1;
-        L64(kR64Eq + 4 * ks + 1) = z2;
-      }
-      token_pass(turn, kTokEq0 + g, q);
-    }
-
-    // =========================== compressor (compressor.rs:700-774)
-    if (flags & kFlagCompressor) {
-      const CompressorParams &cp = P.comp;
-      double d[kChunk], inst_peak_db[kChunk], rms_db[kChunk], weight_db[kChunk];
-      double low_e[kChunk], voiced_e[kChunk], presence_e[kChunk], rms_e[kChunk];
-      // ---- token A: side-chain high-pass + band / rms envelopes (linear recurrences)
-      token_wait(turn, kTokCompA, q);
-      {
-        double rms_env = L64(kR64RmsEnvSq);
-        if (cp.sidechain_highpass_enabled) {
-          double prev_in = L64(kR64ScPrevIn), prev_out = L64(kR64ScPrevOut);
-          double low_env = L64(kR64LowEnv), voiced_env = L64(kR64VoicedEnv), presence_env = L64(kR64PresenceEnv);
-          const double kk = cp.band_env_coeff;
-#pragma unroll
-          for (int k = 0; k < kChunk; ++k)
-            if (k < len) {
-              const double xin = (double)x[k];
-              const double dd = cp.sidechain_highpass_coeff * (prev_out + xin - prev_in);
-              prev_in = xin;
-              prev_out = dd;
-              const double low = xin - dd;
-              const double presence = 0.65 * dd + 0.35 * (dd - low);
-              low_env = kk * low_env + (1.0 - kk) * low * low;
-              voiced_env = kk * voiced_env + (1.0 - kk) * dd * dd;
-              presence_env = kk * presence_env + (1.0 - kk) * presence * presence;
-              rms_env = cp.rms_coeff * rms_env + (1.0 - cp.rms_coeff) * (dd * dd);
-              d[k] = dd;
-              low_e[k] = low_env;
-              voiced_e[k] = voiced_env;
-              presence_e[k] = presence_env;
-              rms_e[k] = rms_env;
-            }
-          L64(kR64ScPrevIn) = prev_in;
-          L64(kR64ScPrevOut) = prev_out;
-          L64(kR64LowEnv) = low_env;
-          L64(kR64VoicedEnv) = voiced_env;
-          L64(kR64PresenceEnv) = presence_env;
-        } else {
-#pragma unroll
-          for (int k = 0; k < kChunk; ++k)
-            if (k < len) {
-              const double dd = (double)x[k];
-              rms_env = cp.rms_coeff * rms_env + (1.0 - cp.rms_coeff) * (dd * dd);
-              d[k] = dd;
-              rms_e[k] = rms_env;
-            }
-        }
-        L64(kR64RmsEnvSq) = rms_env;
-      }
-      token_pass(turn, kTokCompA, q);
-      // ---- feed-forward: detector weight, instantaneous peak and RMS levels in dB
-      double plosive_last = 0.0;
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) {
-          weight_db[k] = 0.0;
-          if (cp.sidechain_highpass_enabled) {  // update_sidechain_band_metrics, compressor.rs:438-449
-            const double low_rms = sqrt(low_e[k]);
-            const double voiced_rms = fmax(sqrt(voiced_e[k]), 1e-8);
-            const double presence_rms = sqrt(presence_e[k]);
-            const double plosive = dclamp(low_rms / voiced_rms, 0.0, 32.0);
-            plosive_last = plosive;
-            const double plosive_amount = dclamp((plosive - 1.25) / (5.0 - 1.25), 0.0, 1.0);
-            const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
-            const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
-            const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
-            weight_db[k] = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
-          }
-          inst_peak_db[k] = lin2db(fabs(d[k]), 1e-10);
-          rms_db[k] = lin2db(sqrt(rms_e[k]), 1e-10);
-        }
-      // ---- token C: log-domain peak envelope (compressor.rs:735-742)
-      double peak_db[kChunk];
-      token_wait(turn, kTokCompC, q);
-      {
-        double pe = L64(kR64PeakEnvDb);
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k)
-          if (k < len) {
-            const double pk = inst_peak_db[k] > pe ? cp.attack_coeff : cp.detector_release_coeff;
-            pe = pk * pe + (1.0 - pk) * inst_peak_db[k];
-            peak_db[k] = pe;
-          }
-        L64(kR64PeakEnvDb) = pe;
-        if (len > 0) L64(kR64Plosive) = plosive_last;  // diagnostic state only (compressor.rs:441)
-      }
-      token_pass(turn, kTokCompC, q);
-      // ---- feed-forward: blended detector level -> static gain-reduction target
-      double target[kChunk];
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) {
-          const double blended = 0.6 * db2lin(peak_db[k]) + 0.4 * db2lin(rms_db[k]);
-          target[k] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_db[k]);
-        }
-      // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
-      double gr_k[kChunk];
-      double makeup_lin;
-      token_wait(turn, kTokCompE, q);
-      {
-        double gr = L64(kR64Gr), fast = L64(kR64FastEnv), slow = L64(kR64SlowEnv);
-        double cur_ms = L64(kR64CurReleaseMs), tgt_ms = L64(kR64TargetReleaseMs);
-        const double rel_coeff = L64(kR64ReleaseCoeff);
-        makeup_lin = L64(kR64MakeupLin);
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k)
-          if (k < len) {
-            if (cp.adaptive_release) {
-              const double sustained = dclamp(slow / (3.0 + 3.0), 0.0, 1.0);
-              const double transient_bias = dclamp((fast - slow) / (3.0 + 4.0), 0.0, 1.0);
-              const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
-              tgt_ms = 50.0 + syllabic * (400.0 - 50.0);
-            } else {
-              tgt_ms = cp.base_release_ms;
-            }
-            if (fabs(tgt_ms - cur_ms) > 1.0) {
-              cur_ms = cp.release_smoothing_coeff * cur_ms + (1.0 - cp.release_smoothing_coeff) * tgt_ms;
-            } else {
-              cur_ms = tgt_ms;
-            }
-            const double tg = target[k];
-            if (!cp.adaptive_release) {
-              const double kk = tg > gr ? cp.attack_coeff : rel_coeff;
-              gr = kk * gr + (1.0 - kk) * tg;
-              fast = gr;
-              slow = 0.0;
-            } else {
-              if (tg > gr) {
-                fast = cp.attack_coeff * gr + (1.0 - cp.attack_coeff) * tg;
+              j = jn;
+              const double tg = peak > ceil_lin ? ceil_lin / peak : 1.0;
+              if (tg < g) {
+                g = tg;
               } else {
-                fast = cp.fast_release_coeff * fast + (1.0 - cp.fast_release_coeff) * tg;
+                g = rc * g + (1.0 - rc) * tg;
               }
-              if (tg > 3.0) {
-                slow = cp.slow_charge_coeff * slow + (1.0 - cp.slow_charge_coeff) * tg;
-              } else {
-                slow *= cp.slow_release_coeff;
-              }
-              gr = fmax(fast, slow);
+              gmin = fmin(gmin, g);
+              const float o = (float)dclamp((double)delayed * g, -ceil_lin, ceil_lin);
+              x[k] = finite_f32(o) ? o : 0.0f;  // TruePeakLimiter input scrub, true_peak.rs:342
+              L32(kR32Tpi + ((nb + k) & (kTpRing - 1))) = x[k];
             }
-            gr_k[k] = gr;
-          }
-        L64(kR64Gr) = gr;
-        L64(kR64FastEnv) = fast;
-        L64(kR64SlowEnv) = slow;
-        L64(kR64CurReleaseMs) = cur_ms;
-        L64(kR64TargetReleaseMs) = tgt_ms;
-        if (last_in_block) {  // update_auto_makeup_gain with auto-makeup off (compressor.rs:604-617)
-          double sm = L64(kR64SmoothedMakeup);
-          const double makeup_coeff = pow(cp.makeup_smoothing_coeff, (double)(blk_len < 1 ? 1 : blk_len));
-          const double tgt = cp.makeup_gain_db;
-          if (fabs(tgt - sm) > 0.1) {
-            sm = makeup_coeff * sm + (1.0 - makeup_coeff) * tgt;
-          } else {
-            sm = tgt;
-          }
-          L64(kR64SmoothedMakeup) = sm;
-          L64(kR64MakeupLin) = db2lin(sm);
-          if (valid && row) row->compressor_gr_db = (float)gr;
+          L64(kR64LimGain) = g;
+          L64(kR64LimGmin) = gmin;
+          L32(kR32LimPrefix) = prefix;
+          if (last_in_block && valid && row)
+            row->limiter_peak_gr_db = gmin < 1.0 ? (float)(-lin2db(gmin, 1e-10)) : 0.0f;
         }
+        token_pass(turn, kTokLim, q);
+        // ---- feed-forward: input-side 4x true peak
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) itp[k] = tp_observe_ring(&l32[kR32Tpi * kLanes], nb + k, lane);
       }
-      token_pass(turn, kTokCompE, q);
-      // ---- feed-forward: apply gain (compressor.rs:771-773)
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) x[k] = (float)((double)x[k] * (db2lin(-gr_k[k]) * makeup_lin));
-    }
 
-    // =========================== limiter + true-peak limiter
-    float itp[kChunk];
-    if (flags & kFlagLimiter) {
-      const double ceil_lin = P.lim.ceiling_linear;
-      const double rc = P.lim.release_coeff;
-      float *ring = &l32[(size_t)kR32LimRing * kLanes];
-      float *suf = &l32[(size_t)(kR32LimRing + W) * kLanes];
-      // ---- token: lookahead limiter (limiter.rs:246-284), sliding max by block prefix/suffix maxima
-      token_wait(turn, kTokLim, q);
+      // ---- token: true-peak gain (true_peak.rs:341-374), chain output, block output stats
+      token_wait(turn, kTokTp, q);
       {
-        double g = L64(kR64LimGain);
-        double gmin = first_in_block ? 1.0 : L64(kR64LimGmin);
-        float prefix = L32(kR32LimPrefix);
-        int j = (int)((n0 + t0) % W);
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k)
-          if (k < len) {
-            const float xin = x[k];
-            const float ax = fabsf(xin);
-            const int jn = (j + 1 == W) ? 0 : j + 1;
-            const float delayed = ring[(size_t)jn * kLanes + lane];
-            const float sfx = (j + 1 < W) ? suf[(size_t)(j + 1) * kLanes + lane] : 0.0f;
-            prefix = (j == 0) ? ax : fmaxf(prefix, ax);
-            const double peak = (double)fmaxf(sfx, prefix);
-            ring[(size_t)j * kLanes + lane] = xin;
-            if (j + 1 == W) {
-              float m = 0.0f;
-              for (int kk = W - 1; kk >= 0; --kk) {
-                m = fmaxf(m, fabsf(ring[(size_t)kk * kLanes + lane]));
-                suf[(size_t)kk * kLanes + lane] = m;
+        double out_sq = first_in_block ? 0.0 : L64(kR64OutSq);
+        float out_peak = first_in_block ? 0.0f : L32(kR32OutPeak);
+        float nonfinite = first_in_block ? 0.0f : L32(kR32NonFinite);
+        float tp_in_peak = 0.0f, tp_gmin = 1.0f, tp_limited = 0.0f;
+        if (flags & kFlagLimiter) {
+          float g = L32(kR32TpGain);
+          tp_in_peak = first_in_block ? 0.0f : L32(kR32TpInPeak);
+          tp_gmin = first_in_block ? 1.0f : L32(kR32TpGmin);
+          tp_limited = first_in_block ? 0.0f : L32(kR32TpLimited);
+          const float rel = P.tp.release_coeff;
+  #pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) {
+              const float delayed = L32(kR32Tpi + ((nb + k - kTpDelay) & (kTpRing - 1)));
+              tp_in_peak = fmaxf(tp_in_peak, itp[k]);
+              float tg = 1.0f;
+              if (itp[k] > tp_ceiling) tg = fclamp((tp_ceiling * 0.999f) / itp[k], 0.0f, 1.0f);
+              if (tg < g) {
+                g = tg;
+                tp_limited = 1.0f;
+              } else {
+                g = rel * g + (1.0f - rel) * tg;
               }
+              tp_gmin = fminf(tp_gmin, g);
+              float o = fclamp(delayed * g, -tp_ceiling, tp_ceiling);
+              if (!finite_f32(o)) o = 0.0f;
+              x[k] = o;
             }
-            j = jn;
-            const double tg = peak > ceil_lin ? ceil_lin / peak : 1.0;
-            if (tg < g) {
-              g = tg;
-            } else {
-              g = rc * g + (1.0 - rc) * tg;
-            }
-            gmin = fmin(gmin, g);
-            const float o = (float)dclamp((double)delayed * g, -ceil_lin, ceil_lin);
-            x[k] = finite_f32(o) ? o : 0.0f;  // TruePeakLimiter input scrub, true_peak.rs:342
-            L32(kR32Tpi + (int)((n0 + t0 + k) & (kTpRing - 1))) = x[k];
-          }
-        L64(kR64LimGain) = g;
-        L64(kR64LimGmin) = gmin;
-        L32(kR32LimPrefix) = prefix;
-        if (last_in_block && valid && row)
-          row->limiter_peak_gr_db = gmin < 1.0 ? (float)(-lin2db(gmin, 1e-10)) : 0.0f;
-      }
-      token_pass(turn, kTokLim, q);
-      // ---- feed-forward: input-side 4x true peak
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) itp[k] = tp_observe_ring(&l32[(size_t)kR32Tpi * kLanes], n0 + t0 + k, lane);
-    }
-
-    // ---- token: true-peak gain (true_peak.rs:341-374), chain output, block output stats
-    token_wait(turn, kTokTp, q);
-    {
-      double out_sq = first_in_block ? 0.0 : L64(kR64OutSq);
-      float out_peak = first_in_block ? 0.0f : L32(kR32OutPeak);
-      float nonfinite = first_in_block ? 0.0f : L32(kR32NonFinite);
-      float tp_in_peak = 0.0f, tp_gmin = 1.0f, tp_limited = 0.0f;
-      if (flags & kFlagLimiter) {
-        float g = L32(kR32TpGain);
-        tp_in_peak = first_in_block ? 0.0f : L32(kR32TpInPeak);
-        tp_gmin = first_in_block ? 1.0f : L32(kR32TpGmin);
-        tp_limited = first_in_block ? 0.0f : L32(kR32TpLimited);
-        const float rel = P.tp.release_coeff;
-#pragma unroll
+          L32(kR32TpGain) = g;
+          L32(kR32TpInPeak) = tp_in_peak;
+          L32(kR32TpGmin) = tp_gmin;
+          L32(kR32TpLimited) = tp_limited;
+        }
+  #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-          if (k < len) {
-            const float delayed = L32(kR32Tpi + (int)((n0 + t0 + k - kTpDelay) & (kTpRing - 1)));
-            tp_in_peak = fmaxf(tp_in_peak, itp[k]);
-            float tg = 1.0f;
-            if (itp[k] > tp_ceiling) tg = fclamp((tp_ceiling * 0.999f) / itp[k], 0.0f, 1.0f);
-            if (tg < g) {
-              g = tg;
-              tp_limited = 1.0f;
+          if (kFull || k < len) {
+            const float o = x[k];
+            float det = o;
+            if (finite_f32(o)) {
+              out_sq += (double)o * (double)o;
             } else {
-              g = rel * g + (1.0f - rel) * tg;
+              nonfinite = 1.0f;
+              det = 0.0f;  // TruePeakDetector::process_block, true_peak.rs:212
             }
-            tp_gmin = fminf(tp_gmin, g);
-            float o = fclamp(delayed * g, -tp_ceiling, tp_ceiling);
-            if (!finite_f32(o)) o = 0.0f;
-            x[k] = o;
+            out_peak = fmaxf(out_peak, fabsf(o));
+            L32(kR32Tpo + ((nb + k) & (kTpRing - 1))) = det;
           }
-        L32(kR32TpGain) = g;
-        L32(kR32TpInPeak) = tp_in_peak;
-        L32(kR32TpGmin) = tp_gmin;
-        L32(kR32TpLimited) = tp_limited;
-      }
-#pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (k < len) {
-          const float o = x[k];
-          float det = o;
-          if (finite_f32(o)) {
-            out_sq += (double)o * (double)o;
-          } else {
-            nonfinite = 1.0f;
-            det = 0.0f;  // TruePeakDetector::process_block, true_peak.rs:212
-          }
-          out_peak = fmaxf(out_peak, fabsf(o));
-          L32(kR32Tpo + (int)((n0 + t0 + k) & (kTpRing - 1))) = det;
+        L64(kR64OutSq) = out_sq;
+        L32(kR32OutPeak) = out_peak;
+        L32(kR32NonFinite) = nonfinite;
+        if (last_in_block && valid && row) {
+          row->output_square_sum = out_sq;
+          row->output_sample_peak = out_peak;
+          row->non_finite_output = nonfinite != 0.0f ? 1u : 0u;
+          row->tp_limiter_input_peak = tp_in_peak;
+          row->tp_limiter_gr_db =
+              (flags & kFlagLimiter) && tp_gmin < 1.0f ? -20.0f * log10f(fmaxf(tp_gmin, 1e-10f)) : 0.0f;
+          row->tp_limited_events = tp_limited != 0.0f ? 1u : 0u;
         }
-      L64(kR64OutSq) = out_sq;
-      L32(kR32OutPeak) = out_peak;
-      L32(kR32NonFinite) = nonfinite;
-      if (last_in_block && valid && row) {
-        row->output_square_sum = out_sq;
-        row->output_sample_peak = out_peak;
-        row->non_finite_output = nonfinite != 0.0f ? 1u : 0u;
-        row->tp_limiter_input_peak = tp_in_peak;
-        row->tp_limiter_gr_db =
-            (flags & kFlagLimiter) && tp_gmin < 1.0f ? -20.0f * log10f(fmaxf(tp_gmin, 1e-10f)) : 0.0f;
-        row->tp_limited_events = tp_limited != 0.0f ? 1u : 0u;
       }
-    }
-    token_pass(turn, kTokTp, q);
+      token_pass(turn, kTokTp, q);
 
-    // ---- feed-forward: store the chunk, output-side 4x true peak (the detector of block_processor.rs:159)
-    if (vec_ok && len == kChunk) {
-      if (valid) {
-        float *dst = &a.out[(int64_t)s * a.stream_stride + t0];
-        if constexpr (kChunk == 2) {
-          *reinterpret_cast<float2 *>(dst) = make_float2(x[0], x[1]);
-        } else {
-#pragma unroll
-          for (int k4 = 0; k4 < kChunk; k4 += 4)
-            *reinterpret_cast<float4 *>(dst + k4) = make_float4(x[k4], x[k4 + 1], x[k4 + 2], x[k4 + 3]);
+      // ---- feed-forward: store the chunk, output-side 4x true peak (the detector of block_processor.rs:159)
+      if (vec_ok && kFull) {
+        if (valid) {
+          float *dst = &a.out[(int64_t)s * a.stream_stride + t0];
+          if constexpr (kChunk == 2) {
+            *reinterpret_cast<float2 *>(dst) = make_float2(x[0], x[1]);
+          } else {
+  #pragma unroll
+            for (int k4 = 0; k4 < kChunk; k4 += 4)
+              *reinterpret_cast<float4 *>(dst + k4) = make_float4(x[k4], x[k4 + 1], x[k4 + 2], x[k4 + 3]);
+          }
         }
+      } else {
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (valid && (kFull || k < len)) {
+            if (a.layout == 0) a.out[(int64_t)s * a.stream_stride + t0 + k] = x[k];
+            else a.out[(t0 + k) * a.stream_stride + s] = x[k];
+          }
       }
-    } else {
-#pragma unroll
+      float otp = 0.0f;
+  #pragma unroll
       for (int k = 0; k < kChunk; ++k)
-        if (valid && k < len) {
-          if (a.layout == 0) a.out[(int64_t)s * a.stream_stride + t0 + k] = x[k];
-          else a.out[(t0 + k) * a.stream_stride + s] = x[k];
-        }
-    }
-    float otp = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kChunk; ++k)
-      if (k < len) otp = fmaxf(otp, tp_observe_ring(&l32[(size_t)kR32Tpo * kLanes], n0 + t0 + k, lane));
-    // ---- token: fold the chunk's output true peak into the block maximum
-    token_wait(turn, kTokFin, q);
-    {
-      const float m = fmaxf(first_in_block ? 0.0f : L32(kR32OutTp), otp);
-      L32(kR32OutTp) = m;
-      if (last_in_block && valid && row) row->output_true_peak = m;
-    }
-    token_pass(turn, kTokFin, q);
+        if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
+      // ---- token: fold the chunk's output true peak into the block maximum
+      token_wait(turn, kTokFin, q);
+      {
+        const float m = fmaxf(first_in_block ? 0.0f : L32(kR32OutTp), otp);
+        L32(kR32OutTp) = m;
+        if (last_in_block && valid && row) row->output_true_peak = m;
+      }
+      token_pass(turn, kTokFin, q);
+    };
+    if (len == kChunk) chunk_body(std::true_type{});
+    else chunk_body(std::false_type{});
   }
   __syncthreads();
   if (tid == 0 && turn[kAbortSlot] != 0 && a.status) atomicExch(a.status, 1);
@@ -697,8 +705,10 @@ hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahe
     case 1602: return launch_variant<16, 2>(args, dyn, stream);
     case 804: return launch_variant<8, 4>(args, dyn, stream);
     case 802: return launch_variant<8, 2>(args, dyn, stream);
+    case 1204: return launch_variant<12, 4>(args, dyn, stream);
+    case 1202: return launch_variant<12, 2>(args, dyn, stream);
     case 0:
-    default: return launch_variant<8, 4>(args, dyn, stream);
+    default: return launch_variant<16, 4>(args, dyn, stream);
   }
 }
 

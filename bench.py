@@ -194,6 +194,7 @@ def main() -> None:
     total_frames = world * streams * n * args.steps
     value = total_frames / elapsed_max
 
+    kernel_name = "chain_lane_kernel" if args.variant == "lane" or args.kernel == 1 else "chain_ring_kernel<" + (args.variant[5:] if args.variant.startswith("ring-") else "16x4") + ">"
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1000.0
         frames_per_launch = streams * n
@@ -216,12 +217,12 @@ def main() -> None:
                 "workload": f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, 10-band EQ + compressor + 2 ms lookahead "
                             f"limiter + 4x true-peak limiter/detector (BASELINE configs[2] shape; RNNoise stage not built yet)",
                 "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
-                "kernel": "chain_lane_kernel", "sharding": f"streams x{world}, no data-path collective",
+                "kernel": kernel_name, "sharding": f"streams x{world}, no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "chain_lane_kernel", "avg_kernel_ms": avg_kernel_s * 1000.0,
+                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0,
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
             },
             "checks": {"output_rms": float(np.sqrt(float(metrics_sum[0]) / (world * streams * n))),

@@ -177,7 +177,7 @@ int64_t af_engine_samples_processed(const af_engine *e);
 /* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO */
 int af_engine_set_kernel(af_engine *e, int32_t kernel);
 /* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
- * (built: 16x4, 16x2, 8x4, 8x2; 0,0 = default) */
+ * (built: 16x4, 16x2, 12x4, 12x2, 8x4, 8x2; 0,0 = default) */
 int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk);
 /* HIP-event timing of the kernels launched by the last process call, in milliseconds,
  * measured on the stream the kernels ran on (0 when timing is disabled) */
