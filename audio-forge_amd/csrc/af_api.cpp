@@ -16,14 +16,15 @@
 namespace af {
 size_t lane_kernel_dynamic_lds(int lookahead_samples);
 hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipStream_t stream);
-size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples);
-hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, int variant,
-                             hipStream_t stream);
+size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
+hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
+                             bool auto_makeup, hipStream_t stream);
+hipError_t launch_merge_prepass_stats(BlockStats *rows, const BlockStats *pre, int64_t n, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
-static_assert(sizeof(af_block_stats) == 56, "stats row size");
+static_assert(sizeof(af_block_stats) == 72, "stats row size");
 
 namespace {
 
@@ -68,6 +69,13 @@ struct af_engine {
   float *d_st32 = nullptr;
   int n_f64 = 0, n_f32 = 0;
   af::BlockStats *d_stats = nullptr;
+  af::BlockStats *d_stats_pre = nullptr;   // rows of the pre-pass launch (auto-makeup)
+  int64_t stats_pre_capacity = 0;
+  af::ChainParams *d_params_pre = nullptr;
+  double *d_vad = nullptr;                 // [blocks][streams] speech posteriors for the next call
+  int64_t vad_capacity = 0, vad_blocks = 0;
+  double vad_reliability = 0.0, noise_floor_db = 0.0, live_noise_reliability = 0.0;
+  bool has_evidence = false;
   int32_t *d_status = nullptr;
   int64_t stats_capacity = 0;  // rows
   float *d_io = nullptr;       // staging for the host entry point
@@ -119,7 +127,11 @@ void export_params(af_engine *e) {
   for (int b = 0; b < af::kNumBands; ++b)
     for (int s = 0; s < p.eq.bands[b].processing_sections; ++s) o.eq[n++] = p.eq.bands[b].sections[s].section();
   o.n_eq_sections = n;
-  o.comp = p.compressor.params();
+  o.comp = p.compressor.params(p.control_block);
+  o.comp.vad_reliability = e->vad_reliability;
+  o.comp.noise_floor_db = e->noise_floor_db;
+  o.comp.live_noise_reliability = e->live_noise_reliability;
+  o.comp.has_evidence = e->has_evidence ? 1 : 0;
   o.lim = p.limiter.params();
   // block_processor.rs:150-151: the TP ceiling follows the limiter ceiling on every block
   af::TruePeakProto tp = p.tp_limiter;
@@ -133,7 +145,8 @@ int upload_initial_state(af_engine *e) {
   const af::ChainProto &p = e->proto;
   const int64_t B = e->n_streams;
   const int nsec = e->host_params.n_eq_sections;
-  const int n64 = af::f64_field_count(nsec);
+  const int meter_slots = (p.compressor_enabled && p.compressor.auto_makeup_enabled) ? e->host_params.comp.meter_slots : 0;
+  const int n64 = af::f64_field_count(nsec, meter_slots);
   const int n32 = af::f32_field_count(p.limiter.lookahead_samples);
   if (e->d_st64 && (n64 != e->n_f64 || n32 != e->n_f32)) {
     AF_HIP(hipFree(e->d_st64));
@@ -176,13 +189,19 @@ int ensure_started(af_engine *e) {
   AF_HIP(hipSetDevice(e->device));
   if (!e->started) {
     if (e->proto.deesser_enabled) return fail(AF_ERR_UNSUPPORTED, "the de-esser stage is not built for the GPU yet");
-    if (e->proto.compressor.auto_makeup_enabled)
-      return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is not built for the GPU yet");
     if (e->proto.limiter_enabled && e->proto.limiter.lookahead_samples > af::kLdsLookaheadMax)
       return fail(AF_ERR_UNSUPPORTED, "limiter lookahead of %d samples exceeds the LDS-resident ring (%d)",
                   e->proto.limiter.lookahead_samples, af::kLdsLookaheadMax);
     export_params(e);
+    if (e->proto.compressor_enabled && e->proto.compressor.auto_makeup_enabled) {
+      if (e->host_params.comp.meter_slots <= 0)
+        return fail(AF_ERR_UNSUPPORTED, "auto-makeup needs a control block that divides the 400 ms loudness window "
+                                        "(e.g. 480 or 960 samples at 48 kHz) and a sample rate the meter supports");
+      if (e->host_params.control_block < 64)
+        return fail(AF_ERR_UNSUPPORTED, "auto-makeup needs control blocks of at least 64 samples");
+    }
     if (!e->d_params) AF_HIP(hipMalloc(&e->d_params, sizeof(af::ChainParams)));
+    if (!e->d_params_pre) AF_HIP(hipMalloc(&e->d_params_pre, sizeof(af::ChainParams)));
     if (!e->d_status) {
       AF_HIP(hipMalloc(&e->d_status, sizeof(int32_t)));
       AF_HIP(hipMemset(e->d_status, 0, sizeof(int32_t)));
@@ -256,6 +275,9 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_st64);
     (void)hipFree(e->d_st32);
     (void)hipFree(e->d_stats);
+    (void)hipFree(e->d_stats_pre);
+    (void)hipFree(e->d_params_pre);
+    (void)hipFree(e->d_vad);
     (void)hipFree(e->d_status);
     (void)hipFree(e->d_io);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -339,6 +361,43 @@ int af_compressor_set_base_release_time(af_engine *e, double v) { AF_SETTER(e->p
 int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_auto_makeup_enabled(on != 0)); }
 int af_compressor_set_target_lufs(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_target_lufs(v)); }
 int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_sidechain_highpass_enabled(on != 0)); }
+
+int af_compressor_set_noise_reference_reliability(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_noise_reference_reliability(v)); }
+
+int af_compressor_set_activity_evidence(af_engine *e, const double *vad_probabilities, int64_t n_blocks, int32_t per_stream,
+                                        double vad_reliability, double noise_floor_db, double live_noise_reliability) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (n_blocks < 0 || (n_blocks > 0 && !vad_probabilities)) return fail(AF_ERR_INVALID_ARGUMENT, "bad VAD array");
+  auto unit = [](double v) { return std::isfinite(v) ? af::clampd(v, 0.0, 1.0) : 0.0; };  // compressor.rs:516-518
+  e->has_evidence = n_blocks > 0;
+  e->vad_reliability = unit(vad_reliability);
+  e->noise_floor_db = std::isfinite(noise_floor_db) ? noise_floor_db : 1.0;  // out of [-120, 0] disables it
+  e->live_noise_reliability = unit(live_noise_reliability);
+  e->vad_blocks = n_blocks;
+  e->params_dirty = true;
+  if (e->started) {  // ChainParams carries the three scalars
+    e->host_params.comp.vad_reliability = e->vad_reliability;
+    e->host_params.comp.noise_floor_db = e->noise_floor_db;
+    e->host_params.comp.live_noise_reliability = e->live_noise_reliability;
+    e->host_params.comp.has_evidence = e->has_evidence ? 1 : 0;
+  }
+  if (n_blocks == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  const int64_t total = n_blocks * e->n_streams;
+  if (total > e->vad_capacity) {
+    if (e->d_vad) AF_HIP(hipFree(e->d_vad));
+    AF_HIP(hipMalloc(&e->d_vad, sizeof(double) * total));
+    e->vad_capacity = total;
+  }
+  if (per_stream) {
+    AF_HIP(hipMemcpy(e->d_vad, vad_probabilities, sizeof(double) * total, hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> expanded((size_t)total);
+    for (int64_t b = 0; b < n_blocks; ++b) std::fill_n(expanded.begin() + b * e->n_streams, e->n_streams, vad_probabilities[b]);
+    AF_HIP(hipMemcpy(e->d_vad, expanded.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+  }
+  return AF_OK;
+}
 
 int af_limiter_set_ceiling(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_ceiling(v)); }
 int af_limiter_set_release_time(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_release_time(v)); }
@@ -432,22 +491,61 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     AF_HIP(hipEventRecord(e->ev_start, stream));
   }
-  const bool ring_fits = af::ring_kernel_dynamic_lds(e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples) <=
-                         af::kMaxLdsBytes;
+  bool any_xf = false;
+  for (int k = 0; k < e->host_params.n_eq_sections; ++k) any_xf |= e->host_params.eq[k].xf_remaining > 0;
+  const bool ring_fits = af::ring_kernel_dynamic_lds(e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples,
+                                                     any_xf) <= af::kMaxLdsBytes;
+  const bool auto_makeup = (e->host_params.flags & af::kFlagCompressor) && e->host_params.comp.auto_makeup_enabled;
   int kernel = e->kernel;
   if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
   if (kernel == AF_KERNEL_PHASED && !ring_fits)
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
+  if (auto_makeup && kernel != AF_KERNEL_PHASED)
+    return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
+  if (auto_makeup && e->has_evidence && e->vad_blocks != blocks)
+    return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
+                (long long)blocks, (long long)e->vad_blocks);
   if (kernel == AF_KERNEL_PHASED) {
     // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
     AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
     if (e->timing) AF_HIP(hipEventRecord(e->ev_start, stream));
-    AF_HIP(af::launch_chain_ring(a, e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples, e->ring_variant,
-                                 stream));
+    if (auto_makeup) {
+      // The compressor needs the RMS of each whole control block of ITS input before the block's first
+      // sample (compressor.rs:710).  Launch 1 runs the front end + EQ into `out` and leaves the block
+      // powers in its stats rows; launch 2 runs compressor -> limiter -> true peak over `out`.
+      if (rows > e->stats_pre_capacity) {
+        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
+        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
+        e->stats_pre_capacity = rows;
+      }
+      af::ChainParams pre = e->host_params, post = e->host_params;
+      pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser)) | af::kFlagPrePass;
+      post.flags &= ~(af::kFlagEq | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub | af::kFlagInputClamp);
+      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->params_dirty = true;  // d_params no longer holds host_params
+      AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
+      af::LaunchArgs a1 = a;
+      a1.params = e->d_params_pre;
+      a1.stats = e->d_stats_pre;
+      AF_HIP(af::launch_chain_ring(a1, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      af::LaunchArgs a2 = a;
+      a2.in = out;
+      a2.pre_stats = e->d_stats_pre;
+      a2.vad_prob = e->has_evidence ? e->d_vad : nullptr;
+      AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, true, stream));
+      AF_HIP(af::launch_merge_prepass_stats(e->d_stats, e->d_stats_pre, rows, stream));
+      e->last_launches = 2;
+    } else {
+      AF_HIP(af::launch_chain_ring(a, e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples, any_xf,
+                                   e->ring_variant, false, stream));
+      e->last_launches = 1;
+    }
   } else {
     AF_HIP(af::launch_chain_lane(a, e->host_params.lim.lookahead_samples, stream));
+    e->last_launches = 1;
   }
-  e->last_launches = 1;
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
   advance_crossfades(e, n_samples);

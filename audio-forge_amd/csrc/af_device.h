@@ -49,6 +49,13 @@ struct CompressorParams {
   double sample_rate;
   // host-evaluated pieces of compute_gain_reduction (compressor.rs:657-678); same IEEE ops, done once
   double comp_factor, knee_start, knee_end, two_knee, two_knee_recip;
+  // auto-makeup (compressor.rs:598-653) and its momentary-loudness meter (loudness.rs:99-135)
+  double kw_b[5], kw_a[5];          // K-weighting as one 4th-order section (BS.1770-4)
+  double makeup_pow_cb, relax_pow_cb, activity_pow_cb;  // coeff^control_block, host pow()
+  double meter_frames;              // samples in the 400 ms window
+  double vad_reliability, noise_floor_db, live_noise_reliability;  // AutoMakeupActivityInput, compressor.rs:32-37
+  int32_t meter_slots;              // control blocks per 400 ms window (0 = meter unavailable)
+  int32_t has_evidence;
   int32_t adaptive_release, sidechain_highpass_enabled, auto_makeup_enabled, pad;
 };
 
@@ -86,6 +93,7 @@ enum ChainFlags : uint32_t {
   kFlagInputClamp = 1u << 6,   // routing.rs:802-823
   kFlagDcBlock = 1u << 7,      // routing.rs:826-843
   kFlagPreHighpass = 1u << 8,
+  kFlagPrePass = 1u << 9,      // first of two launches: front end + EQ only, no detector, no compressor bookkeeping
 };
 
 struct ChainParams {
@@ -117,7 +125,11 @@ enum F64Field : int {
   kEqBase = kDeBand0 + 3 * kDeBandStride,  // then 4 per section: z1 z2 pz1 pz2
   kF64Fixed = kEqBase
 };
-inline int f64_field_count(int n_sections) { return kF64Fixed + 4 * n_sections; }
+// after the EQ sections: the loudness meter (only when auto-makeup is on)
+enum MeterField : int { kMeterV1 = 0, kMeterV2, kMeterV3, kMeterV4, kMeterPos, kMeterRing, kMeterFixed = kMeterRing };
+inline int f64_field_count(int n_sections, int meter_slots = 0) {
+  return kF64Fixed + 4 * n_sections + (meter_slots > 0 ? kMeterFixed + meter_slots : 0);
+}
 
 // f32 plane field indices
 enum F32Field : int {
@@ -137,6 +149,7 @@ struct BlockStats {
   float limiter_peak_gr_db, tp_limiter_gr_db, compressor_gr_db, deesser_gr_db;
   double input_square_sum, output_square_sum;
   uint32_t tp_limited_events, non_finite_output;
+  float makeup_gain_db, makeup_activity, makeup_reliability, pad;  // compressor metering at block end
 };
 
 struct LaunchArgs {
@@ -147,6 +160,8 @@ struct LaunchArgs {
   float *out;
   BlockStats *stats;          // [blocks][n_streams]
   int32_t *status;            // device word: non-zero when a kernel gave up on a token (never expected)
+  const BlockStats *pre_stats;  // rows of the pre-pass launch (compressor-input block power), or null
+  const double *vad_prob;     // [blocks][n_streams] speech posteriors for auto-makeup, or null
   int64_t n_samples;
   int64_t stream_stride;
   int64_t samples_before;     // samples processed by earlier launches (van-Herk phase)

@@ -289,6 +289,41 @@ struct EqProto {
   }
 };
 
+// ---------------------------------------------------------------------- K-weighting
+// ebur128 0.1.10 is not vendored in the reference (Cargo.lock:236-245); this is the filter of
+// ITU-R BS.1770-4 as the published libebur128 design builds it for an arbitrary rate: a high
+// shelf (f0 1681.97 Hz, +4 dB) cascaded with the RLB high-pass (f0 38.14 Hz), expanded into one
+// 4th-order transfer function.  Parity for this block is unpinned.
+inline void kweighting_design(double fs, double b[5], double a[5]) {
+  double f0 = 1681.974450955533, G = 3.999843853973347, Q = 0.7071752369554196;
+  double K = std::tan(kPi * f0 / fs);
+  const double Vh = std::pow(10.0, G / 20.0), Vb = std::pow(Vh, 0.4996667741545416);
+  double pb[3], pa[3] = {1.0, 0.0, 0.0};
+  const double rb[3] = {1.0, -2.0, 1.0};
+  double ra[3] = {1.0, 0.0, 0.0};
+  const double a0 = 1.0 + K / Q + K * K;
+  pb[0] = (Vh + Vb * K / Q + K * K) / a0;
+  pb[1] = 2.0 * (K * K - Vh) / a0;
+  pb[2] = (Vh - Vb * K / Q + K * K) / a0;
+  pa[1] = 2.0 * (K * K - 1.0) / a0;
+  pa[2] = (1.0 - K / Q + K * K) / a0;
+  f0 = 38.13547087602444;
+  Q = 0.5003270373238773;
+  K = std::tan(kPi * f0 / fs);
+  ra[1] = 2.0 * (K * K - 1.0) / (1.0 + K / Q + K * K);
+  ra[2] = (1.0 - K / Q + K * K) / (1.0 + K / Q + K * K);
+  b[0] = pb[0] * rb[0];
+  b[1] = pb[0] * rb[1] + pb[1] * rb[0];
+  b[2] = pb[0] * rb[2] + pb[1] * rb[1] + pb[2] * rb[0];
+  b[3] = pb[1] * rb[2] + pb[2] * rb[1];
+  b[4] = pb[2] * rb[2];
+  a[0] = pa[0] * ra[0];
+  a[1] = pa[0] * ra[1] + pa[1] * ra[0];
+  a[2] = pa[0] * ra[2] + pa[1] * ra[1] + pa[2] * ra[0];
+  a[3] = pa[1] * ra[2] + pa[2] * ra[1];
+  a[4] = pa[2] * ra[2];
+}
+
 // --------------------------------------------------------------------------- compressor
 // Parameter half + the state the setters touch, dsp/compressor.rs:131-404.
 struct CompressorProto {
@@ -356,9 +391,18 @@ struct CompressorProto {
   void set_auto_makeup_enabled(bool on) { auto_makeup_enabled = on && has_meter; if (!on) smoothed_makeup_gain = makeup_gain_db; }
   void set_target_lufs(double v) { target_lufs = clampd(v, -24.0, -12.0); }
   void set_sidechain_highpass_enabled(bool on) { sidechain_highpass_enabled = on; }  // state is still all-zero
+  void set_noise_reference_reliability(double v) { noise_reference_reliability = std::isfinite(v) ? clampd(v, 0.0, 1.0) : 0.0; }
 
-  CompressorParams params() const {
+  CompressorParams params(int control_block) const {
     CompressorParams p{};
+    kweighting_design(sample_rate, p.kw_b, p.kw_a);
+    const int s100 = ((int)sample_rate + 5) / 10;
+    p.meter_frames = 4.0 * s100;
+    p.meter_slots = (has_meter && control_block > 0 && (4 * s100) % control_block == 0 && (4 * s100) / control_block <= 64)
+                        ? (4 * s100) / control_block : 0;
+    p.makeup_pow_cb = std::pow(makeup_smoothing_coeff, (double)control_block);
+    p.relax_pow_cb = std::pow(makeup_silence_relax_coeff, (double)control_block);
+    p.activity_pow_cb = std::pow(speech_activity_smoothing_coeff, (double)control_block);
     p.threshold_db = threshold_db; p.ratio = ratio; p.knee_db = knee_db;
     p.attack_coeff = attack_coeff; p.detector_release_coeff = detector_release_coeff; p.rms_coeff = rms_coeff;
     p.release_smoothing_coeff = release_smoothing_coeff; p.base_release_ms = base_release_ms;

@@ -454,6 +454,10 @@ extern "C" __global__ __launch_bounds__(kLanes) void chain_lane_kernel(LaunchArg
       st.output_square_sum = out_sq;
       st.tp_limited_events = tp_limited;
       st.non_finite_output = non_finite;
+      st.makeup_gain_db = (flags & kFlagCompressor) ? (float)cs.smoothed_makeup : 0.0f;
+      st.makeup_activity = 0.0f;
+      st.makeup_reliability = 0.0f;
+      st.pad = 0.0f;
       a.stats[block_index * NS + s] = st;
     }
   }

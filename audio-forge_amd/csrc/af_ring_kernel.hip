@@ -32,7 +32,7 @@ constexpr int kEqGroup = 5;   // biquad sections per token
 constexpr int kMaxEqGroups = kMaxEqSections / kEqGroup;
 
 // tokens
-enum : int { kTokIn = 0, kTokCompA, kTokCompC, kTokCompE, kTokLim, kTokTp, kTokFin, kTokEq0, kNumTokens = kTokEq0 + kMaxEqGroups };
+enum : int { kTokIn = 0, kTokCompA, kTokCompC, kTokCompE, kTokMeter, kTokLim, kTokTp, kTokFin, kTokEq0, kNumTokens = kTokEq0 + kMaxEqGroups };
 
 // LDS rows, f64 plane (each row = 64 doubles)
 enum : int {
@@ -41,7 +41,10 @@ enum : int {
   kR64PeakEnvDb, kR64RmsEnvSq, kR64Gr, kR64FastEnv, kR64SlowEnv, kR64CurReleaseMs, kR64TargetReleaseMs,
   kR64ReleaseCoeff, kR64SmoothedMakeup, kR64MakeupLin,
   kR64LimGain, kR64LimGmin, kR64InSq, kR64OutSq,
-  kR64Eq  // then 4 rows per section: z1 z2 pz1 pz2
+  // auto-makeup: per-block activity estimate (double-buffered by block parity), meter filter, controller state
+  kR64Activity0, kR64Activity1, kR64Reliab0, kR64Reliab1, kR64MeterV1, kR64MeterV2, kR64MeterV3, kR64MeterV4,
+  kR64MeterAcc, kR64ActScore, kR64ActReliab, kR64CurrentLufs,
+  kR64Eq  // then 2 rows per section (z1 z2), followed by 2 more per section (pz1 pz2) while a crossfade is pending
 };
 // LDS rows, f32 plane (each row = 64 floats)
 enum : int {
@@ -52,8 +55,8 @@ enum : int {
   kR32LimRing = kR32Tpo + kTpRing  // 2*W rows
 };
 
-__host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead) {
-  const size_t rows64 = kR64Eq + 4 * (size_t)n_sections;
+__host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, bool crossfade) {
+  const size_t rows64 = kR64Eq + (crossfade ? 4 : 2) * (size_t)n_sections;
   const size_t rows32 = kR32LimRing + 2 * ((size_t)lookahead + 1);
   return 256 + rows64 * kLanes * sizeof(double) + rows32 * kLanes * sizeof(float);
 }
@@ -95,7 +98,8 @@ __device__ __forceinline__ float tp_observe_ring(const float *ring, int n, int l
   return peak;
 }
 
-template <int kRingWaves, int kChunk>
+// kAuto: the compressor's auto-makeup controller and its loudness meter are compiled in
+template <int kRingWaves, int kChunk, bool kAuto>
 __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const ChainParams &P = *a.params;
@@ -106,7 +110,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 
   int *turn = reinterpret_cast<int *>(lds_raw);
   double *l64 = reinterpret_cast<double *>(lds_raw + 256);
-  const int rows64 = kR64Eq + 4 * P.n_eq_sections;
+  bool any_xf = false;
+  for (int k = 0; k < P.n_eq_sections; ++k) any_xf |= P.eq[k].xf_remaining > 0;
+  const int rows64 = kR64Eq + (any_xf ? 4 : 2) * P.n_eq_sections;
+  const int pz_base = kR64Eq + 2 * P.n_eq_sections;  // rows of the pending-filter memories
   float *l32 = reinterpret_cast<float *>(lds_raw + 256 + (size_t)rows64 * kLanes * sizeof(double));
 #define L64(row) l64[(row)*kLanes + lane]
 #define L32(row) l32[(row)*kLanes + lane]
@@ -134,7 +141,27 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
                        {kR64SmoothedMakeup, kCompSmoothedMakeup}, {kR64LimGain, kLimGain}};
     const int n_m64 = (int)(sizeof(m64) / sizeof(m64[0]));
     for (int k = wave; k < n_m64; k += kRingWaves) L64(m64[k].row) = a.st64[(int64_t)m64[k].field * NS + sc];
-    for (int k = wave; k < 4 * nsec; k += kRingWaves) L64(kR64Eq + k) = a.st64[(int64_t)(kEqBase + k) * NS + sc];
+    for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
+      const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);  // state plane: z1 z2 pz1 pz2 per section
+      const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
+      L64(row) = a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + sc];
+    }
+    if (wave == 1 % kRingWaves) {
+      const int mbase = kF64Fixed + 4 * P.n_eq_sections;
+      const bool meter = kAuto && P.comp.meter_slots > 0;
+      L64(kR64MeterV1) = meter ? a.st64[(int64_t)(mbase + kMeterV1) * NS + sc] : 0.0;
+      L64(kR64MeterV2) = meter ? a.st64[(int64_t)(mbase + kMeterV2) * NS + sc] : 0.0;
+      L64(kR64MeterV3) = meter ? a.st64[(int64_t)(mbase + kMeterV3) * NS + sc] : 0.0;
+      L64(kR64MeterV4) = meter ? a.st64[(int64_t)(mbase + kMeterV4) * NS + sc] : 0.0;
+      L64(kR64MeterAcc) = 0.0;
+      L64(kR64ActScore) = a.st64[(int64_t)kCompActivityScore * NS + sc];
+      L64(kR64ActReliab) = a.st64[(int64_t)kCompActivityReliability * NS + sc];
+      L64(kR64CurrentLufs) = a.st64[(int64_t)kCompCurrentLufs * NS + sc];
+      L64(kR64Activity0) = 0.0;
+      L64(kR64Activity1) = 0.0;
+      L64(kR64Reliab0) = 0.0;
+      L64(kR64Reliab1) = 0.0;
+    }
     if (wave == 0) {
       L64(kR64MakeupLin) = db2lin(a.st64[(int64_t)kCompSmoothedMakeup * NS + sc]);
       L64(kR64LimGmin) = 1.0;
@@ -266,12 +293,12 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         token_wait(turn, kTokEq0 + g, q);
         for (int ks = k0; ks < k1; ++ks) {
           const SectionParams &sp = P.eq[ks];
-          double z1 = L64(kR64Eq + 4 * ks), z2 = L64(kR64Eq + 4 * ks + 1);
+          double z1 = L64(kR64Eq + 2 * ks), z2 = L64(kR64Eq + 2 * ks + 1);
           BiquadCoef c = sp.active;
           int rem = sp.xf_remaining - (int)(t0 < sp.xf_remaining ? t0 : sp.xf_remaining);
           if (rem > 0) {
             const BiquadCoef p = sp.pending;
-            double pz1 = L64(kR64Eq + 4 * ks + 2), pz2 = L64(kR64Eq + 4 * ks + 3);
+            double pz1 = L64(pz_base + 2 * ks), pz2 = L64(pz_base + 2 * ks + 1);
             const double total = (double)sp.xf_total;
   #pragma unroll
             for (int k = 0; k < kChunk; ++k)
@@ -296,8 +323,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
                 }
                 x[k] = (float)y;
               }
-            L64(kR64Eq + 4 * ks + 2) = pz1;
-            L64(kR64Eq + 4 * ks + 3) = pz2;
+            L64(pz_base + 2 * ks) = pz1;
+            L64(pz_base + 2 * ks + 1) = pz2;
           } else {
             if (sp.xf_remaining > 0) c = sp.pending;
   #pragma unroll
@@ -310,8 +337,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
                 x[k] = (float)y;
               }
           }
-          L64(kR64Eq + 4 * ks) = z1;
-          L64(kR64Eq + 4 * ks + 1) = z2;
+          L64(kR64Eq + 2 * ks) = z1;
+          L64(kR64Eq + 2 * ks + 1) = z2;
         }
         token_pass(turn, kTokEq0 + g, q);
       }
@@ -324,6 +351,42 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         // ---- token A: side-chain high-pass + band / rms envelopes (linear recurrences)
         token_wait(turn, kTokCompA, q);
         {
+          if (kAuto && first_in_block) {
+            // estimate_auto_makeup_activity(block_rms_db(buffer), evidence), compressor.rs:528-596,710
+            const double power = a.pre_stats ? a.pre_stats[b * NS + sc].output_square_sum / (double)blk_len : 0.0;
+            const double brms_db = lin2db(sqrt(power), 1e-10);
+            double absolute = 0.0;
+            if (brms_db >= -55.0 && brms_db <= -6.0)
+              absolute = fmin(dclamp(div_known(brms_db + 55.0, 12.0, 1.0 / 12.0), 0.0, 1.0),
+                              dclamp(div_known(-6.0 - brms_db, 6.0, 1.0 / 6.0), 0.0, 1.0));
+            double act = absolute, rel = 1.0;
+            if (cp.has_evidence) {
+              double vad_rel = cp.vad_reliability;
+              double vad_p = a.vad_prob ? a.vad_prob[b * NS + sc] : 0.0;
+              if (!(fabs(vad_p) < HUGE_VAL) || vad_p != vad_p) {
+                vad_rel = 0.0;
+                vad_p = 0.0;
+              }
+              vad_p = dclamp(vad_p, 0.0, 1.0);
+              const double configured = cp.noise_reference_reliability;
+              const double live = cp.live_noise_reliability;
+              double noise_rel = configured > 0.0 ? fmin(live, configured) : live;
+              double relative = 0.0;
+              const double nf = cp.noise_floor_db;
+              if (nf >= -120.0 && nf <= 0.0) {
+                const double e0 = nf + 3.0, e1 = nf + 15.0;
+                const double t = dclamp((brms_db - e0) / (e1 - e0), 0.0, 1.0);
+                relative = t * t * (3.0 - 2.0 * t);
+              } else {
+                noise_rel = 0.0;
+              }
+              const double fallback = noise_rel * relative + (1.0 - noise_rel) * absolute;
+              act = dclamp(vad_rel * vad_p + (1.0 - vad_rel) * fallback, 0.0, 1.0);
+              rel = dclamp(fmax(vad_rel, 0.75 * noise_rel), 0.0, 1.0);
+            }
+            L64((b & 1) ? kR64Activity1 : kR64Activity0) = act;
+            L64((b & 1) ? kR64Reliab1 : kR64Reliab0) = rel;
+          }
           double rms_env = L64(kR64RmsEnvSq);
           if (cp.sidechain_highpass_enabled) {
             double prev_in = L64(kR64ScPrevIn), prev_out = L64(kR64ScPrevOut);
@@ -462,7 +525,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
           L64(kR64SlowEnv) = slow;
           L64(kR64CurReleaseMs) = cur_ms;
           L64(kR64TargetReleaseMs) = tgt_ms;
-          if (last_in_block) {  // update_auto_makeup_gain with auto-makeup off (compressor.rs:604-617)
+          if (last_in_block && valid && row) row->compressor_gr_db = (float)gr;
+          if (last_in_block && !kAuto) {  // update_auto_makeup_gain, auto-makeup off (compressor.rs:604-617)
             double sm = L64(kR64SmoothedMakeup);
             const double makeup_coeff = pow(cp.makeup_smoothing_coeff, (double)(blk_len < 1 ? 1 : blk_len));
             const double tgt = cp.makeup_gain_db;
@@ -473,14 +537,115 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
             }
             L64(kR64SmoothedMakeup) = sm;
             L64(kR64MakeupLin) = db2lin(sm);
-            if (valid && row) row->compressor_gr_db = (float)gr;
+            if (valid && row) row->makeup_gain_db = (float)sm;
           }
         }
         token_pass(turn, kTokCompE, q);
-        // ---- feed-forward: apply gain (compressor.rs:771-773)
+        if constexpr (!kAuto) {
+          // ---- feed-forward: apply gain (compressor.rs:771-773)
   #pragma unroll
-        for (int k = 0; k < kChunk; ++k)
-          if (kFull || k < len) x[k] = (float)((double)x[k] * (db2lin(-gr_k[k]) * makeup_lin));
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) x[k] = (float)((double)x[k] * (db2lin(-gr_k[k]) * makeup_lin));
+        } else {
+          double glin[kChunk];
+  #pragma unroll
+          for (int k = 0; k < kChunk; ++k)
+            if (kFull || k < len) glin[k] = db2lin(-gr_k[k]);
+          // ---- token: makeup gain of THIS block, loudness meter, auto-makeup controller at block end
+          token_wait(turn, kTokMeter, q);
+          {
+            const double mk = L64(kR64MakeupLin);
+            const double act = L64((b & 1) ? kR64Activity1 : kR64Activity0);
+            const double rel = L64((b & 1) ? kR64Reliab1 : kR64Reliab0);
+            const bool fed = act > 0.20 && rel >= 0.35 && cp.meter_slots > 0;  // compressor.rs:714-720
+            double v1 = L64(kR64MeterV1), v2 = L64(kR64MeterV2), v3 = L64(kR64MeterV3), v4 = L64(kR64MeterV4);
+            double acc = first_in_block ? 0.0 : L64(kR64MeterAcc);
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) {
+                x[k] = (float)((double)x[k] * (glin[k] * mk));
+                if (fed) {  // K-weighting, one 4th-order direct-form section (loudness.rs:119-127 over ebur128)
+                  const double v0 = (double)x[k] - cp.kw_a[1] * v1 - cp.kw_a[2] * v2 - cp.kw_a[3] * v3 - cp.kw_a[4] * v4;
+                  const double y = cp.kw_b[0] * v0 + cp.kw_b[1] * v1 + cp.kw_b[2] * v2 + cp.kw_b[3] * v3 + cp.kw_b[4] * v4;
+                  v4 = v3; v3 = v2; v2 = v1; v1 = v0;
+                  acc += y * y;
+                }
+              }
+            if (last_in_block) {
+              const int mbase = kF64Fixed + 4 * P.n_eq_sections;
+              double lufs = L64(kR64CurrentLufs);
+              if (fed) {
+                const double tiny = 2.2250738585072014e-308;
+                if (fabs(v1) < tiny) v1 = 0.0;
+                if (fabs(v2) < tiny) v2 = 0.0;
+                if (fabs(v3) < tiny) v3 = 0.0;
+                if (fabs(v4) < tiny) v4 = 0.0;
+                // 400 ms window = the last meter_slots fed blocks (block energies instead of 19 200 samples)
+                // (the slots live in HBM: written by whichever wave ends a block, so they are read and
+                // written with agent-scope accesses that bypass this CU's L1)
+                const int written = (int)__hip_atomic_load(&a.st64[(int64_t)(mbase + kMeterPos) * NS + sc], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+                const int pos = written + 1 == cp.meter_slots ? 0 : written + 1;
+                if (valid) {
+                  __hip_atomic_store(&a.st64[(int64_t)(mbase + kMeterRing + written) * NS + s], acc, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(&a.st64[(int64_t)(mbase + kMeterPos) * NS + s], (double)pos, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+                }
+                double sum = 0.0;
+                for (int m = 0; m < cp.meter_slots; ++m) {
+                  const double e = m == written ? acc
+                                                : __hip_atomic_load(&a.st64[(int64_t)(mbase + kMeterRing + m) * NS + sc],
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  sum += e;
+                }
+                const double energy = sum / cp.meter_frames;
+                lufs = energy <= 0.0 ? -HUGE_VAL : (double)(float)(10.0 * (log(energy) / log(10.0)) - 0.691);
+                L64(kR64CurrentLufs) = lufs;
+              }
+              // update_auto_makeup_gain, compressor.rs:598-653
+              const bool whole = blk_len == P.control_block;
+              const double elapsed = (double)(blk_len < 1 ? 1 : blk_len);
+              const double mc = whole ? cp.makeup_pow_cb : pow(cp.makeup_smoothing_coeff, elapsed);
+              const double rc2 = whole ? cp.relax_pow_cb : pow(cp.makeup_silence_relax_coeff, elapsed);
+              const double ac = whole ? cp.activity_pow_cb : pow(cp.speech_activity_smoothing_coeff, elapsed);
+              double sm = L64(kR64SmoothedMakeup);
+              const double score = ac * L64(kR64ActScore) + (1.0 - ac) * dclamp(act, 0.0, 1.0);
+              const double relst = dclamp(rel, 0.0, 1.0);
+              L64(kR64ActScore) = score;
+              L64(kR64ActReliab) = relst;
+              if (score < 0.20) {
+                sm = rc2 * sm + (1.0 - rc2) * cp.makeup_gain_db;
+              } else if (relst < 0.35) {
+                const double cap = cp.makeup_gain_db + 3.0 * (relst / 0.35);
+                if (sm > cap) sm = mc * sm + (1.0 - mc) * cap;
+              } else {
+                const double required = cp.target_lufs - lufs;
+                const double reliability_cap = dclamp(12.0 * relst, 3.0, 12.0);
+                const double headroom_cap = dclamp(12.0, 0.0, reliability_cap);  // limiter feedback is 0 offline
+                const double clamped = dclamp(required, 0.0, headroom_cap);
+                if (fabs(clamped - sm) > 0.1) {
+                  sm = mc * sm + (1.0 - mc) * clamped;
+                } else {
+                  sm = clamped;
+                }
+              }
+              L64(kR64SmoothedMakeup) = sm;
+              L64(kR64MakeupLin) = db2lin(sm);
+              if (valid && row) {
+                row->makeup_gain_db = (float)sm;
+                row->makeup_activity = (float)score;
+                row->makeup_reliability = (float)relst;
+              }
+            }
+            L64(kR64MeterV1) = v1;
+            L64(kR64MeterV2) = v2;
+            L64(kR64MeterV3) = v3;
+            L64(kR64MeterV4) = v4;
+            L64(kR64MeterAcc) = acc;
+          }
+          token_pass(turn, kTokMeter, q);
+        }
       }
 
       // =========================== limiter + true-peak limiter
@@ -588,7 +753,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
               det = 0.0f;  // TruePeakDetector::process_block, true_peak.rs:212
             }
             out_peak = fmaxf(out_peak, fabsf(o));
-            L32(kR32Tpo + ((nb + k) & (kTpRing - 1))) = det;
+            if (!(flags & kFlagPrePass)) L32(kR32Tpo + ((nb + k) & (kTpRing - 1))) = det;
           }
         L64(kR64OutSq) = out_sq;
         L32(kR32OutPeak) = out_peak;
@@ -626,9 +791,11 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
           }
       }
       float otp = 0.0f;
+      if (!(flags & kFlagPrePass)) {
   #pragma unroll
-      for (int k = 0; k < kChunk; ++k)
-        if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
+      }
       // ---- token: fold the chunk's output true peak into the block maximum
       token_wait(turn, kTokFin, q);
       {
@@ -645,7 +812,20 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   if (tid == 0 && turn[kAbortSlot] != 0 && a.status) atomicExch(a.status, 1);
 
   // ---------------- write the state back
-  if (valid) {
+  if (valid && (flags & kFlagPrePass)) {
+    // pre-pass launch: only the front end and the EQ advanced
+    for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
+      const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);
+      const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
+      a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + s] = L64(row);
+    }
+    if (wave == 0) {
+      a.st64[(int64_t)kPreZ1 * NS + s] = L64(kR64PreZ1);
+      a.st64[(int64_t)kPreZ2 * NS + s] = L64(kR64PreZ2);
+      a.st32[(int64_t)kDcX1 * NS + s] = L32(kR32DcX1);
+      a.st32[(int64_t)kDcY1 * NS + s] = L32(kR32DcY1);
+    }
+  } else if (valid) {
     struct Map { int row, field; };
     const Map m64[] = {{kR64PreZ1, kPreZ1}, {kR64PreZ2, kPreZ2}, {kR64ScPrevIn, kCompScPrevIn},
                        {kR64ScPrevOut, kCompScPrevOut}, {kR64LowEnv, kCompLowEnv}, {kR64VoicedEnv, kCompVoicedEnv},
@@ -653,10 +833,22 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
                        {kR64RmsEnvSq, kCompRmsEnvSq}, {kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv},
                        {kR64SlowEnv, kCompSlowEnv}, {kR64CurReleaseMs, kCompCurReleaseMs},
                        {kR64TargetReleaseMs, kCompTargetReleaseMs}, {kR64SmoothedMakeup, kCompSmoothedMakeup},
-                       {kR64LimGain, kLimGain}};
+                       {kR64LimGain, kLimGain}, {kR64ActScore, kCompActivityScore},
+                       {kR64ActReliab, kCompActivityReliability}, {kR64CurrentLufs, kCompCurrentLufs}};
     const int n_m64 = (int)(sizeof(m64) / sizeof(m64[0]));
     for (int k = wave; k < n_m64; k += kRingWaves) a.st64[(int64_t)m64[k].field * NS + s] = L64(m64[k].row);
-    for (int k = wave; k < 4 * nsec; k += kRingWaves) a.st64[(int64_t)(kEqBase + k) * NS + s] = L64(kR64Eq + k);
+    for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
+      const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);
+      const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
+      a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + s] = L64(row);
+    }
+    if (wave == 1 % kRingWaves && kAuto && P.comp.meter_slots > 0) {
+      const int mbase = kF64Fixed + 4 * P.n_eq_sections;
+      a.st64[(int64_t)(mbase + kMeterV1) * NS + s] = L64(kR64MeterV1);
+      a.st64[(int64_t)(mbase + kMeterV2) * NS + s] = L64(kR64MeterV2);
+      a.st64[(int64_t)(mbase + kMeterV3) * NS + s] = L64(kR64MeterV3);
+      a.st64[(int64_t)(mbase + kMeterV4) * NS + s] = L64(kR64MeterV4);
+    }
     if (wave == 0) {
       const double tau = fmax(L64(kR64CurReleaseMs), 0.001) / 1000.0;  // compressor.rs:760-761
       a.st64[(int64_t)kCompReleaseCoeff * NS + s] =
@@ -680,26 +872,42 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 #undef L32
 }
 
-size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples) { return ring_lds_bytes(n_sections, lookahead_samples); }
+// After a two-launch run the chain-input statistics live in the pre-pass rows: fold them in.
+__global__ void merge_prepass_stats_kernel(BlockStats *rows, const BlockStats *pre, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    rows[i].input_square_sum = pre[i].input_square_sum;
+    rows[i].input_sample_peak = pre[i].input_sample_peak;
+  }
+}
+hipError_t launch_merge_prepass_stats(BlockStats *rows, const BlockStats *pre, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(merge_prepass_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, pre, n);
+  return hipGetLastError();
+}
 
-template <int kRingWaves, int kChunk>
+size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade) {
+  return ring_lds_bytes(n_sections, lookahead_samples, crossfade);
+}
+
+template <int kRingWaves, int kChunk, bool kAuto = false>
 static hipError_t launch_variant(const LaunchArgs &args, size_t dyn, hipStream_t stream) {
   const int groups = (args.n_streams + kLanes - 1) / kLanes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) return err;
     attr_set = true;
   }
-  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream, args);
+  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk, kAuto>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream, args);
   return hipGetLastError();
 }
 
 // `variant` = waves * 100 + chunk; 0 picks the default
-hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, int variant,
-                             hipStream_t stream) {
-  const size_t dyn = ring_lds_bytes(n_sections, lookahead_samples);
+hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
+                             bool auto_makeup, hipStream_t stream) {
+  const size_t dyn = ring_lds_bytes(n_sections, lookahead_samples, crossfade);
+  if (auto_makeup) return launch_variant<8, 4, true>(args, dyn, stream);  // one build: 256 VGPRs, no spills
   switch (variant) {
     case 1604: return launch_variant<16, 4>(args, dyn, stream);
     case 1602: return launch_variant<16, 2>(args, dyn, stream);

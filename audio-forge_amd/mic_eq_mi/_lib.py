@@ -49,6 +49,10 @@ class BlockStats(C.Structure):
         ("output_square_sum", C.c_double),
         ("true_peak_limited_events", C.c_uint32),
         ("non_finite_output", C.c_uint32),
+        ("compressor_makeup_gain_db", C.c_float),
+        ("auto_makeup_activity", C.c_float),
+        ("auto_makeup_reliability", C.c_float),
+        ("reserved", C.c_float),
     ]
 
 
@@ -88,6 +92,8 @@ SIGNATURES = {
     "af_compressor_set_auto_makeup_enabled": (C.c_int, [_vp, _i32]),
     "af_compressor_set_target_lufs": (C.c_int, [_vp, _d]),
     "af_compressor_set_sidechain_highpass_enabled": (C.c_int, [_vp, _i32]),
+    "af_compressor_set_noise_reference_reliability": (C.c_int, [_vp, _d]),
+    "af_compressor_set_activity_evidence": (C.c_int, [_vp, _dp, _i64, _i32, _d, _d, _d]),
     "af_limiter_set_ceiling": (C.c_int, [_vp, _d]),
     "af_limiter_set_release_time": (C.c_int, [_vp, _d]),
     "af_limiter_set_lookahead_ms": (C.c_int, [_vp, _d]),

@@ -35,6 +35,10 @@ STATS_DTYPE = np.dtype(
         ("output_square_sum", "<f8"),
         ("true_peak_limited_events", "<u4"),
         ("non_finite_output", "<u4"),
+        ("compressor_makeup_gain_db", "<f4"),
+        ("auto_makeup_activity", "<f4"),
+        ("auto_makeup_reliability", "<f4"),
+        ("reserved", "<f4"),
     ]
 )
 assert STATS_DTYPE.itemsize == C.sizeof(BlockStats)
@@ -418,6 +422,75 @@ def simulate_auto_eq_chain(audio, sample_rate: float, bands: Sequence[tuple[floa
     if _get(settings, "return_output_audio", False):
         d["output_audio"] = output[0].tolist()  # the reference returns a Python list of floats
     return d
+
+
+# ------------------------------------------------------ simulate_auto_makeup_control
+def simulate_auto_makeup_control(audio, sample_rate: float, vad_probabilities: Sequence[float], noise_floor_db: float,
+                                 noise_reliability: float, settings: Mapping[str, object] | None = None) -> dict[str, Any]:
+    """python_api.rs:118-276: the compressor's auto-makeup controller at the 10 ms control cadence."""
+    control_block = 480
+    if not np.isfinite(sample_rate) or sample_rate <= 0.0:
+        raise ValueError("sample_rate must be positive and finite")
+    if not np.isfinite(noise_floor_db) or not np.isfinite(noise_reliability) or not 0.0 <= noise_reliability <= 1.0:
+        raise ValueError("noise evidence must be finite and reliability must be between 0 and 1")
+    vad = np.ascontiguousarray(vad_probabilities, dtype=np.float64)
+    if vad.size and (not np.all(np.isfinite(vad)) or vad.min() < 0.0 or vad.max() > 1.0):
+        raise ValueError("VAD probabilities must be finite and between 0 and 1")
+    audio = _audio_1d(audio)
+    n = audio.size
+    block_count = -(-n // control_block)
+    if vad.size and vad.size != block_count:
+        raise ValueError(f"expected {block_count} VAD probabilities at the 10 ms control cadence, got {vad.size}")
+    vad_reliability = _get(settings, "vad_reliability", 1.0)
+    if not np.isfinite(vad_reliability) or not 0.0 <= vad_reliability <= 1.0:
+        raise ValueError("vad_reliability must be finite and between 0 and 1")
+    engine = Engine(sample_rate, 1)
+    try:
+        engine.set_eq_enabled(0)
+        engine.set_limiter_enabled(0)
+        engine.set_compressor_enabled(1)
+        engine.compressor_set_threshold(_get(settings, "threshold_db", -24.0))
+        engine.compressor_set_ratio(_get(settings, "ratio", 3.0))
+        engine.compressor_set_attack_time(_get(settings, "attack_ms", 10.0))
+        engine.compressor_set_release_time(_get(settings, "release_ms", 180.0))
+        engine.compressor_set_makeup_gain(_get(settings, "makeup_gain_db", 0.0))
+        engine.compressor_set_auto_makeup_enabled(1)
+        engine.compressor_set_target_lufs(_get(settings, "target_lufs", -18.0))
+        engine.compressor_set_noise_reference_reliability(float(noise_reliability))
+        engine.compressor_set_adaptive_release(int(_get(settings, "adaptive_release", True)))
+        engine.compressor_set_sidechain_highpass_enabled(int(_get(settings, "sidechain_highpass_enabled", True)))
+        engine.set_control_block_samples(control_block)
+        engine.set_input_scrub_enabled(0)
+        dp = C.POINTER(C.c_double)
+        _lib.check(engine._lib.af_compressor_set_activity_evidence(
+            engine._h, vad.ctypes.data_as(dp), int(vad.size), 0, float(vad_reliability), float(noise_floor_db),
+            float(noise_reliability)))
+        started = time.perf_counter()
+        output = engine.process(audio.reshape(1, -1))[0] if n else audio.copy()
+        runtime_ms = (time.perf_counter() - started) * 1000.0
+        rows = engine.block_stats()[:, 0]
+    finally:
+        engine.close()
+    lengths = _block_lengths(n, control_block).astype(np.float64)
+    per_block_ms = runtime_ms / max(block_count, 1)
+    result: dict[str, Any] = {
+        "control_block_size": control_block,
+        "control_cadence_hz": sample_rate / control_block,
+        "processed_samples": int(n),
+        "makeup_gain_db": rows["compressor_makeup_gain_db"].astype(np.float32).tolist(),
+        "activity": rows["auto_makeup_activity"].astype(np.float32).tolist(),
+        "reliability": rows["auto_makeup_reliability"].astype(np.float32).tolist(),
+        "gain_reduction_db": rows["compressor_gain_reduction_db"].astype(np.float32).tolist(),
+        "input_rms_db": _linear_to_db(np.sqrt(rows["input_square_sum"] / np.maximum(lengths, 1.0)).astype(np.float32)).tolist(),
+        "output_rms_db": _linear_to_db(np.sqrt(rows["output_square_sum"] / np.maximum(lengths, 1.0)).astype(np.float32)).tolist(),
+        # the batch engine has no per-block host timer: the launch time is spread evenly over the blocks
+        "p95_block_runtime_ms": per_block_ms,
+        "p99_block_runtime_ms": per_block_ms,
+        "max_block_runtime_ms": per_block_ms,
+    }
+    if _get(settings, "return_output_audio", False):
+        result["output_audio"] = output.tolist()
+    return result
 
 
 # -------------------------------------------------------------------- simulate_eq_v2

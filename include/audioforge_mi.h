@@ -64,6 +64,12 @@ typedef struct af_block_stats {
   double output_square_sum;
   uint32_t true_peak_limited_events; /* 0 or 1 per block, true_peak.rs:376 */
   uint32_t non_finite_output;
+  /* Compressor::current_makeup_gain / auto_makeup_activity / auto_makeup_activity_reliability at the end of
+   * the block (compressor.rs:346-363) -- the traces of simulate_auto_makeup_control */
+  float compressor_makeup_gain_db;
+  float auto_makeup_activity;
+  float auto_makeup_reliability;
+  float reserved;
 } af_block_stats;
 
 /* layout of the audio buffers handed to af_engine_process_* */
@@ -132,6 +138,15 @@ int af_compressor_set_base_release_time(af_engine *e, double release_ms);
 int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t enabled);
 int af_compressor_set_target_lufs(af_engine *e, double target_lufs);
 int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t enabled);
+int af_compressor_set_noise_reference_reliability(af_engine *e, double reliability); /* compressor.rs:351-353 */
+/* AutoMakeupActivityInput (compressor.rs:32-37) for the NEXT af_engine_process_* call: one speech
+ * posterior per control block (shared by all streams, or [block][stream] when per_stream != 0) plus
+ * the three scalars simulate_auto_makeup_control passes (python_api.rs:211-219).  n_blocks = 0
+ * clears the evidence (process_block_inplace without evidence, compressor.rs:695-697).  May be
+ * called between process calls. */
+int af_compressor_set_activity_evidence(af_engine *e, const double *vad_probabilities, int64_t n_blocks,
+                                        int32_t per_stream, double vad_reliability, double noise_floor_db,
+                                        double live_noise_reliability);
 
 /* ---- Limiter: rust-core/src/dsp/limiter.rs:139-184 ------------------------------ */
 int af_limiter_set_ceiling(af_engine *e, double ceiling_db);

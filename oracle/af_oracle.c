@@ -2095,3 +2095,99 @@ void afo_kat_signal(float *out, size_t n_blocks, uint64_t noise_state, double f0
     }
   }
 }
+
+/* ------------------------------------------- simulate_auto_makeup_control */
+/* audio/processor/python_api.rs:118-276.  traces: [6][block_count] f32 rows =
+ * makeup_gain_db, activity, reliability, gain_reduction_db, input_rms_db, output_rms_db */
+int afo_simulate_auto_makeup_control(const float *audio, size_t n, double sample_rate,
+                                     const double *vad_probabilities, size_t n_vad,
+                                     double noise_floor_db, double noise_reliability,
+                                     const afo_makeup_settings *s, float *traces, float *out_audio) {
+  const size_t CONTROL_BLOCK_SIZE = 480;
+  if (!isfinite(sample_rate) || sample_rate <= 0.0) return -1;
+  if (!isfinite(noise_floor_db) || !isfinite(noise_reliability) || noise_reliability < 0.0 ||
+      noise_reliability > 1.0)
+    return -2;
+  for (size_t i = 0; i < n_vad; ++i)
+    if (!isfinite(vad_probabilities[i]) || vad_probabilities[i] < 0.0 || vad_probabilities[i] > 1.0) return -3;
+  size_t block_count = (n + CONTROL_BLOCK_SIZE - 1) / CONTROL_BLOCK_SIZE;
+  if (n_vad != 0 && n_vad != block_count) return -4;
+  if (!isfinite(s->vad_reliability) || s->vad_reliability < 0.0 || s->vad_reliability > 1.0) return -5;
+  afo_compressor c;
+  afo_compressor_init(&c, s->threshold_db, s->ratio, s->attack_ms, s->release_ms, s->makeup_gain_db, 6.0,
+                      sample_rate);
+  afo_compressor_set_auto_makeup_enabled(&c, 1);
+  afo_compressor_set_target_lufs(&c, s->target_lufs);
+  afo_compressor_set_noise_reference_reliability(&c, noise_reliability);
+  afo_compressor_set_adaptive_release(&c, s->adaptive_release);
+  afo_compressor_set_sidechain_highpass_enabled(&c, s->sidechain_highpass_enabled);
+  float block[480];
+  for (size_t b = 0; b < block_count; ++b) {
+    size_t start = b * CONTROL_BLOCK_SIZE;
+    size_t len = n - start < CONTROL_BLOCK_SIZE ? n - start : CONTROL_BLOCK_SIZE;
+    memcpy(block, audio + start, sizeof(float) * len);
+    double sq = 0.0;
+    for (size_t i = 0; i < len; ++i) sq += (double)block[i] * (double)block[i];
+    float input_rms = (float)sqrt(sq / (double)(len > 1 ? len : 1));
+    afo_auto_makeup_input ev;
+    const afo_auto_makeup_input *evp = NULL;
+    if (b < n_vad) {
+      ev.vad_probability = vad_probabilities[b];
+      ev.vad_reliability = s->vad_reliability;
+      ev.noise_floor_db = noise_floor_db;
+      ev.live_noise_reliability = noise_reliability;
+      evp = &ev;
+    }
+    afo_compressor_process_block(&c, block, len, evp);
+    sq = 0.0;
+    for (size_t i = 0; i < len; ++i) sq += (double)block[i] * (double)block[i];
+    float output_rms = (float)sqrt(sq / (double)(len > 1 ? len : 1));
+    traces[0 * block_count + b] = (float)c.smoothed_makeup_gain;
+    traces[1 * block_count + b] = (float)c.speech_activity_score;
+    traces[2 * block_count + b] = (float)c.auto_makeup_activity_reliability;
+    traces[3 * block_count + b] = (float)c.current_gain_reduction_db;
+    traces[4 * block_count + b] = afo_linear_to_db_f32(input_rms);
+    traces[5 * block_count + b] = afo_linear_to_db_f32(output_rms);
+    if (out_audio) memcpy(out_audio + start, block, sizeof(float) * len);
+  }
+  afo_compressor_free(&c);
+  return 0;
+}
+
+/* lib.rs:290-298 over dsp/loudness.rs:43-83 (ebur128 Mode::I, gated; spec-restated, unpinned) */
+int afo_measure_integrated_loudness(const float *audio, size_t n, uint32_t sample_rate, double *lufs) {
+  afo_loudness m;
+  if (afo_loudness_init(&m, sample_rate)) return -1;
+  if (n == 0) { afo_loudness_free(&m); return -2; }
+  for (size_t i = 0; i < n; ++i)
+    if (!isfinite(audio[i])) { afo_loudness_free(&m); return -3; }
+  /* 400 ms blocks with 75 % overlap (hop = 100 ms), absolute gate -70 LUFS, relative gate -10 LU */
+  size_t s100 = (sample_rate + 5) / 10, blk = s100 * 4;
+  double *y = (double *)malloc(sizeof(double) * n);
+  double v[5] = {0, 0, 0, 0, 0};
+  for (size_t i = 0; i < n; ++i) {
+    v[0] = (double)audio[i] - m.a[1] * v[1] - m.a[2] * v[2] - m.a[3] * v[3] - m.a[4] * v[4];
+    y[i] = m.b[0] * v[0] + m.b[1] * v[1] + m.b[2] * v[2] + m.b[3] * v[3] + m.b[4] * v[4];
+    v[4] = v[3]; v[3] = v[2]; v[2] = v[1]; v[1] = v[0];
+  }
+  size_t nblk = n >= blk ? (n - blk) / s100 + 1 : 0;
+  double *e = (double *)malloc(sizeof(double) * (nblk ? nblk : 1));
+  for (size_t b = 0; b < nblk; ++b) {
+    double sum = 0.0;
+    for (size_t i = 0; i < blk; ++i) sum += y[b * s100 + i] * y[b * s100 + i];
+    e[b] = sum / (double)blk;
+  }
+  const double abs_gate = pow(10.0, (-70.0 + 0.691) / 10.0);
+  double sum = 0.0; size_t cnt = 0;
+  for (size_t b = 0; b < nblk; ++b) if (e[b] >= abs_gate) { sum += e[b]; cnt++; }
+  int rc = 0;
+  if (cnt == 0) { rc = -4; }
+  else {
+    double rel_gate = (sum / (double)cnt) * pow(10.0, -10.0 / 10.0);
+    sum = 0.0; cnt = 0;
+    for (size_t b = 0; b < nblk; ++b) if (e[b] >= abs_gate && e[b] >= rel_gate) { sum += e[b]; cnt++; }
+    if (cnt == 0) rc = -4; else *lufs = 10.0 * log10(sum / (double)cnt) - 0.691;
+  }
+  free(y); free(e); afo_loudness_free(&m);
+  return rc;
+}

@@ -390,6 +390,18 @@ int afo_eq_magnitude_response_v2(const double *freqs, size_t n,
                                  const afo_eq_band_config bands[AFO_NUM_BANDS], double sample_rate,
                                  double *out);
 
+/* ------------------------------------------- simulate_auto_makeup_control */
+/* python_api.rs:166-185 defaults */
+typedef struct {
+  double threshold_db, ratio, attack_ms, release_ms, makeup_gain_db, target_lufs, vad_reliability;
+  int32_t adaptive_release, sidechain_highpass_enabled;
+} afo_makeup_settings;
+int afo_simulate_auto_makeup_control(const float *audio, size_t n, double sample_rate,
+                                     const double *vad_probabilities, size_t n_vad,
+                                     double noise_floor_db, double noise_reliability,
+                                     const afo_makeup_settings *s, float *traces, float *out_audio);
+int afo_measure_integrated_loudness(const float *audio, size_t n, uint32_t sample_rate, double *lufs);
+
 /* ------------------------------------------------------------- utilities */
 double afo_time_constant_to_coeff(double time_ms, double sample_rate);
 double afo_db_to_linear(double db);

@@ -121,6 +121,19 @@ class EqV2Result(C.Structure):
     ]
 
 
+class MakeupSettings(C.Structure):
+    _fields_ = [
+        ("threshold_db", C.c_double), ("ratio", C.c_double), ("attack_ms", C.c_double), ("release_ms", C.c_double),
+        ("makeup_gain_db", C.c_double), ("target_lufs", C.c_double), ("vad_reliability", C.c_double),
+        ("adaptive_release", C.c_int32), ("sidechain_highpass_enabled", C.c_int32),
+    ]
+
+
+MAKEUP_DEFAULTS = dict(threshold_db=-24.0, ratio=3.0, attack_ms=10.0, release_ms=180.0, makeup_gain_db=0.0,
+                       target_lufs=-18.0, vad_reliability=1.0, adaptive_release=True, sidechain_highpass_enabled=True)
+MAKEUP_TRACES = ("makeup_gain_db", "activity", "reliability", "gain_reduction_db", "input_rms_db", "output_rms_db")
+
+
 class BlockStats(C.Structure):
     _fields_ = [
         ("input_sample_peak", C.c_float),
@@ -186,6 +199,10 @@ def lib() -> C.CDLL:
         L.afo_eq_magnitude_response_v2.restype = i
         L.afo_eq_magnitude_response_v2.argtypes = [dp, sz, C.POINTER(EqBandConfig), d, dp]
         L.afo_kat_signal.argtypes = [fp, sz, C.c_uint64, d, d]
+        L.afo_simulate_auto_makeup_control.restype = i
+        L.afo_simulate_auto_makeup_control.argtypes = [fp, sz, d, dp, sz, d, d, C.POINTER(MakeupSettings), fp, fp]
+        L.afo_measure_integrated_loudness.restype = i
+        L.afo_measure_integrated_loudness.argtypes = [fp, sz, C.c_uint32, dp]
         L.afo_time_constant_to_coeff.restype = d
         L.afo_time_constant_to_coeff.argtypes = [d, d]
         L.afo_db_to_linear.restype = d
@@ -324,3 +341,38 @@ class Chain:
     def process_block(self, block: np.ndarray) -> BlockStats:
         assert block.dtype == np.float32 and block.flags.c_contiguous
         return self.L.afo_chain_process_block(self.h, _fptr(block), block.size)
+
+
+def simulate_auto_makeup_control(audio, sample_rate, vad_probabilities, noise_floor_db, noise_reliability, settings=None) -> dict:
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    cfg = dict(MAKEUP_DEFAULTS)
+    want_audio = False
+    for k, v in (settings or {}).items():
+        if k == "return_output_audio":
+            want_audio = bool(v)
+        else:
+            cfg[k] = v
+    s = MakeupSettings(**{k: (int(v) if isinstance(v, bool) else v) for k, v in cfg.items()})
+    vad = np.ascontiguousarray(vad_probabilities, dtype=np.float64)
+    blocks = (audio.size + 479) // 480
+    traces = np.zeros((6, blocks), dtype=np.float32)
+    out = np.zeros_like(audio)
+    rc = lib().afo_simulate_auto_makeup_control(_fptr(audio), audio.size, float(sample_rate), _dptr(vad), vad.size,
+                                                float(noise_floor_db), float(noise_reliability), C.byref(s),
+                                                traces.ctypes.data_as(C.POINTER(C.c_float)), _fptr(out))
+    if rc != 0:
+        raise ValueError(f"simulate_auto_makeup_control rejected its arguments ({rc})")
+    d = {name: traces[k].copy() for k, name in enumerate(MAKEUP_TRACES)}
+    d.update(control_block_size=480, control_cadence_hz=sample_rate / 480.0, processed_samples=int(audio.size))
+    if want_audio:
+        d["output_audio"] = out
+    return d
+
+
+def measure_integrated_loudness(audio, sample_rate: int) -> float:
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    v = C.c_double(0.0)
+    rc = lib().afo_measure_integrated_loudness(_fptr(audio), audio.size, int(sample_rate), C.byref(v))
+    if rc != 0:
+        raise ValueError(f"integrated loudness unavailable ({rc})")
+    return v.value

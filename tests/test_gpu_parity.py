@@ -7,6 +7,8 @@ Tolerances (north_star: per-sample RMS error <= 1e-5 vs the reference):
     f64, which can flip the last bit of an f32 output sample now and then -> max |err| <= 2e-7
     (two ulp of f32 at 0.5 full scale) and RMS error <= 2e-8, i.e. 500x inside the budget.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -264,3 +266,39 @@ def test_setters_refused_after_streaming_started(mi):
     eng.reset()
     eng.compressor_set_threshold(-10.0)
     eng.close()
+
+
+def test_auto_makeup_control_traces(mi, oracle):
+    """simulate_auto_makeup_control (python_api.rs:118-276): per-block controller traces + audio.
+    The loudness meter (ebur128, not vendored) is spec-restated on both sides; its 400 ms window is
+    summed per control block on the GPU, hence the 1e-6 dB tolerance on the traces."""
+    if not os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring"):
+        pytest.skip("auto-makeup lives in the token-ring kernel")
+    x = S.kat_signal(400)
+    vad = (np.abs(np.sin(np.arange(400) * 0.05)) > 0.3).astype(float)
+    for probs, settings in ((vad, {"return_output_audio": True}), ([], {"return_output_audio": True, "adaptive_release": False})):
+        want = oracle.simulate_auto_makeup_control(x, 48_000.0, probs, -60.0, 0.8, settings)
+        got = mi.simulate_auto_makeup_control(x, 48_000.0, probs, -60.0, 0.8, settings)
+        for key in ("makeup_gain_db", "activity", "reliability", "gain_reduction_db", "input_rms_db", "output_rms_db"):
+            a, b = np.asarray(got[key], dtype=np.float64), np.asarray(want[key], dtype=np.float64)
+            assert a.shape == b.shape and np.max(np.abs(a - b)) <= 2e-5, (key, float(np.max(np.abs(a - b))))
+        max_abs, rms = _err(got["output_audio"], want["output_audio"])
+        assert max_abs <= 5e-7 and rms <= 5e-8, (max_abs, rms)
+        assert max(want["makeup_gain_db"]) > 1.0  # the controller is really moving
+
+
+def test_auto_makeup_inside_full_chain(mi, oracle):
+    """compressor_auto_makeup_enabled=True through simulate_auto_eq_chain (EQ ahead of the compressor:
+    two launches on the GPU)."""
+    if not os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring"):
+        pytest.skip("auto-makeup lives in the token-ring kernel")
+    settings = dict(S.limiter_settings(2.0), compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0)
+    bands = list(S.LIMITER_BANDS)
+    bands[3] = (bands[3][0], 4.0, 1.2)
+    audio = S.batch_signal(3, 400)
+    out, results = mi.simulate_auto_eq_chain_batch(audio, 48_000, bands, settings)
+    for s in range(3):
+        want = oracle.simulate_auto_eq_chain(audio[s], 48_000, bands, settings)
+        max_abs, rms = _err(out[s], want["output_audio"])
+        assert max_abs <= 5e-7 and rms <= 5e-8, (s, max_abs, rms)
+        _compare_dicts(results[s], want)
