@@ -12,6 +12,7 @@
 #include "../../include/audioforge_mi.h"
 #include "af_device.h"
 #include "af_host.hpp"
+#include "af_suppressor_host.hpp"
 
 namespace af {
 size_t lane_kernel_dynamic_lds(int lookahead_samples);
@@ -81,6 +82,8 @@ struct af_engine {
   float *d_io = nullptr;       // staging for the host entry point
   int64_t io_capacity = 0;     // floats
   hipStream_t last_stream = nullptr;
+  af::SuppressorHost supp;
+  int supp_window_frames = 50;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 
   af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}
@@ -208,6 +211,11 @@ int ensure_started(af_engine *e) {
     }
     int rc = upload_initial_state(e);
     if (rc) return rc;
+    if (e->supp.enabled) {
+      if (e->proto.sample_rate != 48000.0)
+        return fail(AF_ERR_INVALID_ARGUMENT, "the RNNoise suppressor runs at 48 kHz only (rnnoise.rs:3,46)");
+      AF_HIP(e->supp.reset_state(e->n_streams));
+    }
     e->params_dirty = true;
     e->started = true;
     e->samples_processed = 0;
@@ -282,6 +290,10 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_io);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+  }
+  if (e->supp.d_blob || e->supp.d_state || e->supp.d_xh) {
+    (void)hipSetDevice(e->device);
+    e->supp.release_all();
   }
   delete e;
 }
@@ -417,6 +429,38 @@ int af_deesser_set_attack_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesse
 int af_deesser_set_release_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_release_ms(v)); }
 int af_deesser_set_max_reduction_db(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_max_reduction_db(v)); }
 
+// ---- RNNoise suppressor (rust-core/src/dsp/rnnoise.rs) ----
+int af_engine_set_suppressor_enabled(af_engine *e, int32_t on) { AF_SETTER(e->supp.enabled = on != 0); }
+int af_engine_set_suppressor_strength(af_engine *e, float strength) {  // rnnoise.rs:67-72; allowed while streaming
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  e->supp.strength = af::clampf(strength, 0.0f, 1.0f);
+  return AF_OK;
+}
+int af_suppressor_set_raw_protocol(af_engine *e, int32_t on) { AF_SETTER(e->supp.raw_protocol = on != 0); }
+int af_suppressor_set_synthetic_weights(af_engine *e, uint64_t seed) {
+  AF_SETTER((af::synthetic_weights(e->supp.weights, seed), e->supp.weights_dirty = true));
+}
+int af_suppressor_load_weights(af_engine *e, const int8_t *blob, size_t bytes) {
+  if (!blob || bytes != sizeof(af::RnnWeightsI8))
+    return fail(AF_ERR_INVALID_ARGUMENT, "weight blob must be %zu bytes (the fifteen int8 arrays of the RNNoise model)",
+                sizeof(af::RnnWeightsI8));
+  AF_SETTER((std::memcpy(&e->supp.weights, blob, bytes), e->supp.weights_dirty = true));
+}
+int32_t af_suppressor_latency_samples(const af_engine *) { return af::kRnnFrame; }  // rnnoise.rs:313-315
+// test tap: one (frame, stream) record of the LAST window: Ex Ep Exp feat[44] gains_raw gains silence pitch, then X, P
+int af_suppressor_debug_read(af_engine *e, int32_t frame, int32_t stream, float *rec_out, float *x_out, float *p_out) {
+  if (!e || !e->supp.d_rec) return fail(AF_ERR_STATE, "no suppressor window has run");
+  if (frame < 0 || frame >= e->supp.ws_frames || stream < 0 || stream >= e->n_streams)
+    return fail(AF_ERR_INVALID_ARGUMENT, "frame/stream out of range");
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipDeviceSynchronize());
+  const size_t cell = (size_t)frame * e->n_streams + stream;
+  AF_HIP(hipMemcpy(rec_out, e->supp.d_rec + cell, sizeof(af::SuppFrameRec), hipMemcpyDeviceToHost));
+  if (x_out) AF_HIP(hipMemcpy(x_out, e->supp.d_X + cell * af::kRnnFreq, sizeof(float2) * af::kRnnFreq, hipMemcpyDeviceToHost));
+  if (p_out) AF_HIP(hipMemcpy(p_out, e->supp.d_P + cell * af::kRnnFreq, sizeof(float2) * af::kRnnFreq, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
 int af_engine_set_kernel(af_engine *e, int32_t kernel) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
   if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_PHASED) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
@@ -465,25 +509,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipMalloc(&e->d_stats, sizeof(af::BlockStats) * rows));
     e->stats_capacity = rows;
   }
-  if (e->params_dirty) {
-    AF_HIP(hipMemcpyAsync(e->d_params, &e->host_params, sizeof(af::ChainParams), hipMemcpyHostToDevice, stream));
-    // the host struct may change right after the launch (crossfade bookkeeping): wait for the copy
-    AF_HIP(hipStreamSynchronize(stream));
-    e->params_dirty = false;
-  }
-  af::LaunchArgs a{};
-  a.params = e->d_params;
-  a.st64 = e->d_st64;
-  a.st32 = e->d_st32;
-  a.in = in;
-  a.out = out;
-  a.stats = e->d_stats;
-  a.status = e->d_status;
-  a.n_samples = n_samples;
-  a.stream_stride = stream_stride;
-  a.samples_before = e->samples_processed;
-  a.n_streams = e->n_streams;
-  a.layout = layout;
+  // ---- RNNoise suppressor ahead of the chain (realtime order, dsp_loop.rs:1222-1250,1521-1599)
+  af::ChainParams run = e->host_params;  // what the chain launch of THIS call uses
+  bool run_modified = false;
+  const float *chain_in = in;
+  bool any_xf = false;
+  for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
   if (e->timing) {
     if (!e->ev_start) {
       AF_HIP(hipEventCreate(&e->ev_start));
@@ -491,11 +522,74 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     AF_HIP(hipEventRecord(e->ev_start, stream));
   }
-  bool any_xf = false;
-  for (int k = 0; k < e->host_params.n_eq_sections; ++k) any_xf |= e->host_params.eq[k].xf_remaining > 0;
-  const bool ring_fits = af::ring_kernel_dynamic_lds(e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples,
-                                                     any_xf) <= af::kMaxLdsBytes;
-  const bool auto_makeup = (e->host_params.flags & af::kFlagCompressor) && e->host_params.comp.auto_makeup_enabled;
+  af::LaunchArgs a{};
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.out = out;
+  a.status = e->d_status;
+  a.n_samples = n_samples;
+  a.stream_stride = stream_stride;
+  a.samples_before = e->samples_processed;
+  a.n_streams = e->n_streams;
+  a.layout = layout;
+  if (e->supp.enabled) {
+    if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
+    if (n_samples % af::kRnnFrame != 0)
+      return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
+                  af::kRnnFrame);
+    if (e->supp.weights_dirty) AF_HIP(e->supp.upload());
+    const uint32_t front = af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
+    if (run.flags & front) {
+      // front end (clamp + DC block + 80 Hz HP) as its own launch so the suppressor sees filtered audio
+      const size_t need = af::ring_kernel_dynamic_lds(0, run.lim.lookahead_samples, false);
+      if (need > af::kMaxLdsBytes) return fail(AF_ERR_UNSUPPORTED, "front-end pre-pass does not fit in LDS");
+      af::ChainParams pre = run;
+      pre.flags = (pre.flags & (front | af::kFlagInputScrub)) | af::kFlagPrePass;
+      pre.n_eq_sections = run.n_eq_sections;
+      if (rows > e->stats_pre_capacity) {
+        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
+        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
+        e->stats_pre_capacity = rows;
+      }
+      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      af::LaunchArgs a0 = a;
+      a0.params = e->d_params_pre;
+      a0.in = chain_in;
+      a0.stats = e->d_stats_pre;
+      AF_HIP(af::launch_chain_ring(a0, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      e->last_launches += 1;
+      chain_in = out;
+      run.flags &= ~(front | af::kFlagInputScrub);
+      run_modified = true;
+    }
+    const int64_t frames = n_samples / af::kRnnFrame;
+    const int window = (int)std::min<int64_t>(frames, e->supp_window_frames);
+    AF_HIP(e->supp.ensure_workspace(e->n_streams, window));
+    for (int64_t f0 = 0; f0 < frames; f0 += window) {
+      af::SuppArgs sa{};
+      sa.in = chain_in;
+      sa.out = out;
+      sa.xh = e->supp.d_xh;
+      sa.X = e->supp.d_X;
+      sa.P = e->supp.d_P;
+      sa.rec = e->supp.d_rec;
+      sa.state = e->supp.d_state;
+      sa.stream_stride = stream_stride;
+      sa.n_streams = e->n_streams;
+      sa.n_frames = (int)std::min<int64_t>(window, frames - f0);
+      sa.frame0 = f0;
+      sa.strength = e->supp.strength;
+      sa.smoothing_coeff = 1.0f - std::exp(-((480.0f / 48000.0f) / (15.0f / 1000.0f)));  // rnnoise.rs:45-51
+      sa.raw_protocol = e->supp.raw_protocol ? 1 : 0;
+      AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
+      e->last_launches += 4;
+    }
+    chain_in = out;
+  }
+
+  const bool ring_fits = af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
+  const bool auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
   int kernel = e->kernel;
   if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
   if (kernel == AF_KERNEL_PHASED && !ring_fits)
@@ -505,10 +599,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (auto_makeup && e->has_evidence && e->vad_blocks != blocks)
     return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
                 (long long)blocks, (long long)e->vad_blocks);
+  a.in = chain_in;
+  a.stats = e->d_stats;
+  a.params = e->d_params;
   if (kernel == AF_KERNEL_PHASED) {
     // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
     AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
-    if (e->timing) AF_HIP(hipEventRecord(e->ev_start, stream));
     if (auto_makeup) {
       // The compressor needs the RMS of each whole control block of ITS input before the block's first
       // sample (compressor.rs:710).  Launch 1 runs the front end + EQ into `out` and leaves the block
@@ -518,7 +614,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
         e->stats_pre_capacity = rows;
       }
-      af::ChainParams pre = e->host_params, post = e->host_params;
+      af::ChainParams pre = run, post = run;
       pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser)) | af::kFlagPrePass;
       post.flags &= ~(af::kFlagEq | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub | af::kFlagInputClamp);
       AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
@@ -536,15 +632,24 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       a2.vad_prob = e->has_evidence ? e->d_vad : nullptr;
       AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, true, stream));
       AF_HIP(af::launch_merge_prepass_stats(e->d_stats, e->d_stats_pre, rows, stream));
-      e->last_launches = 2;
+      e->last_launches += 3;
     } else {
-      AF_HIP(af::launch_chain_ring(a, e->host_params.n_eq_sections, e->host_params.lim.lookahead_samples, any_xf,
-                                   e->ring_variant, false, stream));
-      e->last_launches = 1;
+      if (e->params_dirty || run_modified) {
+        AF_HIP(hipMemcpyAsync(e->d_params, &run, sizeof run, hipMemcpyHostToDevice, stream));
+        AF_HIP(hipStreamSynchronize(stream));  // `run` is a stack copy
+        e->params_dirty = run_modified;
+      }
+      AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      e->last_launches += 1;
     }
   } else {
-    AF_HIP(af::launch_chain_lane(a, e->host_params.lim.lookahead_samples, stream));
-    e->last_launches = 1;
+    if (e->params_dirty || run_modified) {
+      AF_HIP(hipMemcpyAsync(e->d_params, &run, sizeof run, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->params_dirty = run_modified;
+    }
+    AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
+    e->last_launches += 1;
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;

@@ -1,0 +1,89 @@
+// af_suppressor.h -- data shared between the host side and the kernels of the RNNoise suppressor
+// (rust-core/src/dsp/rnnoise.rs over nnnoiseless 0.5.2; see af_rnnoise.hip for the parity note).
+#pragma once
+#include <stdint.h>
+
+namespace af {
+
+constexpr int kRnnFrame = 480;
+constexpr int kRnnWindow = 960;
+constexpr int kRnnFreq = 481;
+constexpr int kRnnBands = 22;
+constexpr int kRnnFeat = 42;
+constexpr int kRnnFeatPad = 44;
+constexpr int kPitchMin = 60;
+constexpr int kPitchMax = 768;
+constexpr int kPitchBuf = 1728;
+constexpr int kCepsMem = 8;
+
+// ---- per-stream persistent state, one row of `SuppState::kCount` floats per stream -------------
+struct SuppState {
+  enum : int {
+    kHist = 0,                          // last 1728 high-passed model-input samples (pitch_buf)
+    kHpMem = kHist + kPitchBuf,         // 2
+    kLastPeriod = kHpMem + 2,           // int stored as float
+    kLastGain,
+    kMemId,                             // cepstral ring write index (int as float)
+    kCeps,                              // 8 x 22
+    kLastG = kCeps + kCepsMem * kRnnBands,  // 22
+    kVadState = kLastG + kRnnBands,     // 24
+    kNoiseState = kVadState + 24,       // 48
+    kDenoiseState = kNoiseState + 48,   // 96
+    kSynthMem = kDenoiseState + 96,     // 480
+    kSmoothedStrength = kSynthMem + kRnnFrame,
+    kCount = ((kSmoothedStrength + 1 + 3) / 4) * 4
+  };
+};
+
+// ---- per (frame, stream) workspace record -------------------------------------------------------
+struct SuppFrameRec {
+  float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands];
+  float feat[kRnnFeatPad];
+  float gains_raw[kRnnBands];  // network output (what pitch_filter sees)
+  float gains[kRnnBands];      // after g = max(g, 0.6 lastg)
+  int32_t silence;
+  int32_t pitch_index;
+};
+
+// ---- network weights on the device: f32, padded to the 16x16x4 matrix-core tiles ------------------
+// Each matrix is [K_pad][N_pad] row-major (k = input index, n = output unit); GRU layers hold three
+// of them (z, r, h) over the concatenated input [layer input | recurrent state].
+struct RnnLayerDims { int k_in, k_rec, k_pad, n, n_pad; };
+constexpr RnnLayerDims kDimDense{42, 0, 44, 24, 32};
+constexpr RnnLayerDims kDimVad{24, 24, 48, 24, 32};
+constexpr RnnLayerDims kDimNoise{90, 48, 140, 48, 48};
+constexpr RnnLayerDims kDimDenoise{114, 96, 212, 96, 96};
+constexpr RnnLayerDims kDimOut{96, 0, 96, 22, 32};
+
+struct RnnDeviceWeights {
+  const float *dense_w, *dense_b;           // [44][32], [32]
+  const float *vad_w[3], *vad_b[3];         // [48][32]
+  const float *noise_w[3], *noise_b[3];     // [140][48]
+  const float *den_w[3], *den_b[3];         // [212][96]
+  const float *out_w, *out_b;               // [96][32]
+  const float *tansig;                      // [201]
+};
+
+struct SuppTables {
+  const float *half_window;   // [480]
+  const float *dct;           // [22*22]
+  const float2 *twiddle;      // [960] exp(-2 pi i k / 960)
+};
+
+struct SuppArgs {
+  const float *in;            // chain input, [stream][stride]
+  float *out;                 // suppressor output, same layout
+  float *xh;                  // [stream][1728 + n_frames*480] scaled + high-passed model input
+  float2 *X, *P;              // [frame][stream][481]
+  SuppFrameRec *rec;          // [frame][stream]
+  float *state;               // [stream][SuppState::kCount]
+  int64_t stream_stride;
+  int32_t n_streams;
+  int32_t n_frames;           // frames in this window
+  int64_t frame0;             // first frame of the window inside `in`
+  float strength;             // wet/dry target (rnnoise.rs:70-79)
+  float smoothing_coeff;      // rnnoise.rs:45-51
+  int32_t raw_protocol;       // 1: rnnoise_benchmark.rs scaling (clamp*32768, no mix)
+};
+
+}  // namespace af

@@ -37,6 +37,8 @@ _OPERATORS = (
     "eq_magnitude_response",
     "eq_magnitude_response_v2",
     "measure_integrated_loudness",
+    "suppress",
+    "rnnoise_benchmark",
 )
 
 CORE_AVAILABLE = _core_module is not None

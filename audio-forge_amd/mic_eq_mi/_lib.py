@@ -76,6 +76,13 @@ SIGNATURES = {
     "af_engine_set_input_scrub_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_set_input_clamp_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_set_prefilter_enabled": (C.c_int, [_vp, _i32, _i32]),
+    "af_engine_set_suppressor_enabled": (C.c_int, [_vp, _i32]),
+    "af_engine_set_suppressor_strength": (C.c_int, [_vp, _f]),
+    "af_suppressor_set_synthetic_weights": (C.c_int, [_vp, C.c_uint64]),
+    "af_suppressor_load_weights": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "af_suppressor_set_raw_protocol": (C.c_int, [_vp, _i32]),
+    "af_suppressor_latency_samples": (_i32, [_vp]),
+    "af_suppressor_debug_read": (C.c_int, [_vp, _i32, _i32, _fp, _fp, _fp]),
     "af_eq_set_band_frequency": (C.c_int, [_vp, _i32, _d]),
     "af_eq_set_band_gain": (C.c_int, [_vp, _i32, _d]),
     "af_eq_set_band_q": (C.c_int, [_vp, _i32, _d]),
@@ -127,7 +134,7 @@ SIGNATURES = {
 # entry points whose return value is data, not an af_status
 VALUE_FUNCTIONS = {
     "af_version", "af_last_error", "af_device_count", "af_engine_n_streams", "af_limiter_ceiling_db",
-    "af_limiter_lookahead_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy",
+    "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy",
 }
 
 _lib = None

@@ -424,6 +424,65 @@ def simulate_auto_eq_chain(audio, sample_rate: float, bands: Sequence[tuple[floa
     return d
 
 
+# ----------------------------------------------------------------------- suppressor
+def suppress(audio: np.ndarray, strength: float = 1.0, weight_seed: int | None = None, raw_protocol: bool = False,
+             device: int = 0) -> np.ndarray:
+    """RNNoiseProcessor::process_frames (rust-core/src/dsp/rnnoise.rs:122-164) over [n_streams, n] or [n] audio.
+
+    Only whole 480-sample frames are produced (a shorter tail stays "buffered", as in the reference).
+    `raw_protocol=True` is the scaling of bin/rnnoise_benchmark.rs (clamp(+-1)*32768, no wet/dry mix).
+    """
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    squeeze = a.ndim == 1
+    if squeeze:
+        a = a.reshape(1, -1)
+    frames = a.shape[1] // 480
+    a = np.ascontiguousarray(a[:, : frames * 480])
+    if frames == 0:
+        return a[0] if squeeze else a
+    engine = Engine(48_000.0, a.shape[0], device)
+    try:
+        engine.set_eq_enabled(0)
+        engine.set_compressor_enabled(0)
+        engine.set_limiter_enabled(0)
+        engine.set_suppressor_enabled(1)
+        engine.set_suppressor_strength(float(strength))
+        engine.suppressor_set_raw_protocol(int(raw_protocol))
+        if weight_seed is not None:
+            engine.suppressor_set_synthetic_weights(int(weight_seed))
+        engine.set_control_block_samples(480)
+        out = engine.process(a)
+    finally:
+        engine.close()
+    return out[0] if squeeze else out
+
+
+def rnnoise_benchmark(input_path: str, output_path: str, metadata_path: str, weight_seed: int | None = None) -> dict:
+    """File protocol of rust-core/src/bin/rnnoise_benchmark.rs:51-117 (`<in.f32> <out.f32> <meta.json>`),
+    the boundary python/tools/evaluate_rnnoise_backends.py:106-125 drives."""
+    import json
+
+    data = np.fromfile(input_path, dtype="<f4")
+    n = data.size
+    frames = -(-n // 480)
+    padded = np.zeros(frames * 480, dtype=np.float32)
+    padded[:n] = data
+    started = time.perf_counter()
+    out = suppress(padded, 1.0, weight_seed, raw_protocol=True) if frames else padded
+    elapsed = time.perf_counter() - started
+    out[:n].astype("<f4").tofile(output_path)
+    per_frame = elapsed / max(frames, 1)
+    meta = {
+        "frames": int(frames), "samples": int(n), "elapsed_seconds": elapsed,
+        "rtf": elapsed / max(n / 48_000.0, 1e-12),
+        # one batched launch covers every frame: the per-frame percentiles are the mean frame time
+        "frame_p95_seconds": per_frame, "frame_p99_seconds": per_frame, "frame_max_seconds": per_frame,
+    }
+    with open(metadata_path, "w", encoding="utf-8") as fh:
+        json.dump(meta, fh)
+    return meta
+
+
 # ------------------------------------------------------ simulate_auto_makeup_control
 def simulate_auto_makeup_control(audio, sample_rate: float, vad_probabilities: Sequence[float], noise_floor_db: float,
                                  noise_reliability: float, settings: Mapping[str, object] | None = None) -> dict[str, Any]:

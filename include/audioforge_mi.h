@@ -118,6 +118,25 @@ int af_engine_set_input_clamp_enabled(af_engine *e, int32_t enabled);
 /* apply_input_pre_filter: DC block + 80 Hz high-pass, routing.rs:826-843 */
 int af_engine_set_prefilter_enabled(af_engine *e, int32_t enabled, int32_t apply_fixed_highpass);
 
+/* ---- RNNoise suppressor: rust-core/src/dsp/rnnoise.rs (RNNoiseProcessor) -------------------------
+ * Runs between the front end and the EQ (dsp_loop.rs:1521-1599).  48 kHz only; n_samples of every
+ * process call must then be a multiple of 480 (one frame).  Output is delayed by one frame
+ * (latency_samples() = 480, rnnoise.rs:313-315).  The network weights of nnnoiseless 0.5.2 are not
+ * available offline: engines start on seeded synthetic weights in the real layout; load the real
+ * ones with af_suppressor_load_weights (blob = the model's fifteen int8 arrays: input_dense w,b;
+ * vad_gru w,u,b; vad_output w,b; noise_gru w,u,b; denoise_gru w,u,b; denoise_output w,b). */
+int af_engine_set_suppressor_enabled(af_engine *e, int32_t enabled);
+int af_engine_set_suppressor_strength(af_engine *e, float strength);  /* rnnoise.rs:67-72, live */
+int af_suppressor_set_synthetic_weights(af_engine *e, uint64_t seed);
+int af_suppressor_load_weights(af_engine *e, const int8_t *blob, size_t bytes);
+/* 1: the file protocol of bin/rnnoise_benchmark.rs:51-117 (clamp(+-1)*32768 in, /32768 out, no mix) */
+int af_suppressor_set_raw_protocol(af_engine *e, int32_t enabled);
+int32_t af_suppressor_latency_samples(const af_engine *e);
+/* test tap: the analysis record (158 floats/ints) and spectra X, P (481 complex each) of one
+ * (frame, stream) cell of the last suppressor window */
+int af_suppressor_debug_read(af_engine *e, int32_t frame, int32_t stream, float *record, float *x_spectrum,
+                             float *p_spectrum);
+
 /* ---- ParametricEQ: rust-core/src/dsp/eq.rs --------------------------------------- */
 int af_eq_set_band_frequency(af_engine *e, int32_t band, double frequency_hz); /* eq.rs:419-425 */
 int af_eq_set_band_gain(af_engine *e, int32_t band, double gain_db);           /* eq.rs:406-412 */

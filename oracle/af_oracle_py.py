@@ -203,6 +203,10 @@ def lib() -> C.CDLL:
         L.afo_simulate_auto_makeup_control.argtypes = [fp, sz, d, dp, sz, d, d, C.POINTER(MakeupSettings), fp, fp]
         L.afo_measure_integrated_loudness.restype = i
         L.afo_measure_integrated_loudness.argtypes = [fp, sz, C.c_uint32, dp]
+        L.afo_rnnoise_benchmark_frames.argtypes = [fp, fp, sz, C.c_uint64]
+        L.afo_suppressor_init.argtypes = [vp, f, C.c_uint64]
+        L.afo_suppressor_process.restype = sz
+        L.afo_suppressor_process.argtypes = [vp, fp, fp, sz]
         L.afo_time_constant_to_coeff.restype = d
         L.afo_time_constant_to_coeff.argtypes = [d, d]
         L.afo_db_to_linear.restype = d
@@ -376,3 +380,21 @@ def measure_integrated_loudness(audio, sample_rate: int) -> float:
     if rc != 0:
         raise ValueError(f"integrated loudness unavailable ({rc})")
     return v.value
+
+
+def rnnoise_benchmark_frames(audio, weight_seed: int = 0x5EED) -> np.ndarray:
+    """bin/rnnoise_benchmark.rs:51-117 protocol over the RNNoise restatement (parity unpinned)."""
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    out = np.zeros_like(audio)
+    lib().afo_rnnoise_benchmark_frames(_fptr(audio), _fptr(out), audio.size, C.c_uint64(weight_seed))
+    return out
+
+
+def suppressor_process(audio, strength: float = 1.0, weight_seed: int = 0x5EED) -> np.ndarray:
+    """RNNoiseProcessor (rnnoise.rs:122-164) over whole frames; returns len(audio)//480*480 samples."""
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    state = C.create_string_buffer(1 << 18)  # afo_suppressor is ~140 KB
+    lib().afo_suppressor_init(state, float(strength), C.c_uint64(weight_seed))
+    out = np.zeros_like(audio)
+    n = lib().afo_suppressor_process(state, _fptr(out), _fptr(audio), audio.size)
+    return out[:n]

@@ -1,0 +1,675 @@
+/*
+ * af_rnnoise.c -- CPU restatement of the RNNoise suppressor behind
+ * rust-core/src/dsp/rnnoise.rs (TEST INFRASTRUCTURE ONLY, see af_oracle.h).
+ *
+ * PARITY UNPINNED.  The wrapper half (frame buffering, soft clip, x32768 scaling, wet/dry
+ * smoothing: rnnoise.rs:45-164) is restated from the reference text.  The core,
+ * `nnnoiseless::DenoiseState::process_frame` (Cargo.lock:605-613, call site rnnoise.rs:142-143),
+ * is a third-party crate that is not vendored under /root/reference and whose trained weights
+ * are embedded in the crate; what follows restates the published RNNoise algorithm that crate
+ * ports (Valin, "A Hybrid DSP/Deep Learning Approach to Real-Time Full-Band Speech Enhancement":
+ * 480-sample frames, 960-point Vorbis-window STFT, 22 Bark-like bands, 42 features with pitch
+ * analysis, dense(42->24) -> GRU24 -> GRU48 -> GRU96 -> dense(96->22), pitch comb filter,
+ * band-gain interpolation, overlap-add) and runs it on seeded synthetic int8 weights in the real
+ * layer layout.  The reference's own tests for this stage assert only frame counts and finiteness
+ * (rnnoise.rs:355-450), so nothing here can be pinned against golden data.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "af_rnnoise.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+#define FRAME AFO_RNN_FRAME
+#define WINDOW 960
+#define FREQ 481
+#define PMIN 60
+#define PMAX 768
+#define PFRAME 960
+#define PBUF 1728
+#define NB AFO_RNN_BANDS
+#define CEPS_MEM 8
+#define NDELTA 6
+#define NFEAT AFO_RNN_FEATURES
+
+static const int eband5ms[NB] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+
+/* ------------------------------------------------------------- tables */
+static float half_window[FRAME];
+static float dct_table[NB * NB];
+static float tansig_table[201];
+static float tw_re[WINDOW], tw_im[WINDOW];
+static int tables_ready = 0;
+
+static void init_tables(void) {
+  if (tables_ready) return;
+  for (int i = 0; i < FRAME; ++i) {
+    double s = sin(.5 * M_PI * (i + .5) / FRAME);
+    half_window[i] = (float)sin(.5 * M_PI * s * s);
+  }
+  for (int i = 0; i < NB; ++i)
+    for (int j = 0; j < NB; ++j) {
+      double v = cos((i + .5) * j * M_PI / NB);
+      if (j == 0) v *= sqrt(.5);
+      dct_table[i * NB + j] = (float)v;
+    }
+  for (int i = 0; i <= 200; ++i) tansig_table[i] = (float)tanh(0.04 * i);
+  for (int i = 0; i < WINDOW; ++i) {
+    tw_re[i] = (float)cos(-2.0 * M_PI * i / WINDOW);
+    tw_im[i] = (float)sin(-2.0 * M_PI * i / WINDOW);
+  }
+  tables_ready = 1;
+}
+
+/* --------------------------------------------------------------- FFT-960
+ * Mixed-radix decimation-in-time (960 = 4*4*4*3*5), f32 arithmetic, twiddles rounded from f64.
+ * out = (1/960) * sum_n in[n] exp(-2 pi i k n / 960)   (the forward scaling of the Opus FFT) */
+typedef struct { float r, i; } cpx;
+
+static void fft_rec(const cpx *in, cpx *out, int n, int stride) {
+  if (n == 1) { out[0] = in[0]; return; }
+  int p = (n % 4 == 0) ? 4 : (n % 3 == 0) ? 3 : 5;
+  int m = n / p;
+  cpx tmp[WINDOW];
+  for (int q = 0; q < p; ++q) fft_rec(in + q * stride, tmp + q * m, m, stride * p);
+  for (int k = 0; k < m; ++k) {
+    for (int r = 0; r < p; ++r) {
+      int kk = k + r * m; /* output bin */
+      float sr = 0.0f, si = 0.0f;
+      for (int q = 0; q < p; ++q) {
+        int t = (int)(((long)q * kk * (WINDOW / n)) % WINDOW);
+        float wr = tw_re[t], wi = tw_im[t];
+        float xr = tmp[q * m + k].r, xi = tmp[q * m + k].i;
+        sr += xr * wr - xi * wi;
+        si += xr * wi + xi * wr;
+      }
+      out[kk].r = sr;
+      out[kk].i = si;
+    }
+  }
+}
+
+static void forward_transform(cpx *out /*FREQ*/, const float *in /*WINDOW*/) {
+  cpx x[WINDOW], y[WINDOW];
+  for (int i = 0; i < WINDOW; ++i) { x[i].r = in[i]; x[i].i = 0.0f; }
+  fft_rec(x, y, WINDOW, 1);
+  const float s = 1.0f / WINDOW;
+  for (int i = 0; i < FREQ; ++i) { out[i].r = y[i].r * s; out[i].i = y[i].i * s; }
+}
+
+static void inverse_transform(float *out /*WINDOW*/, const cpx *in /*FREQ*/) {
+  cpx x[WINDOW], y[WINDOW];
+  for (int i = 0; i < FREQ; ++i) x[i] = in[i];
+  for (int i = FREQ; i < WINDOW; ++i) { x[i].r = x[WINDOW - i].r; x[i].i = -x[WINDOW - i].i; }
+  fft_rec(x, y, WINDOW, 1);
+  /* forward FFT of a conjugate-symmetric spectrum; time reversal gives the inverse */
+  out[0] = y[0].r;
+  for (int i = 1; i < WINDOW; ++i) out[i] = y[WINDOW - i].r;
+}
+
+static void apply_window(float *x) {
+  for (int i = 0; i < FRAME; ++i) {
+    x[i] *= half_window[i];
+    x[WINDOW - 1 - i] *= half_window[i];
+  }
+}
+
+/* ------------------------------------------------------------ band tools */
+static void compute_band_energy(float *bandE, const cpx *X) {
+  float sum[NB] = {0};
+  for (int i = 0; i < NB - 1; ++i) {
+    int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
+    for (int j = 0; j < band_size; ++j) {
+      float frac = (float)j / band_size;
+      const cpx v = X[(eband5ms[i] << 2) + j];
+      float tmp = v.r * v.r + v.i * v.i;
+      sum[i] += (1 - frac) * tmp;
+      sum[i + 1] += frac * tmp;
+    }
+  }
+  sum[0] *= 2;
+  sum[NB - 1] *= 2;
+  memcpy(bandE, sum, sizeof sum);
+}
+
+static void compute_band_corr(float *bandE, const cpx *X, const cpx *P) {
+  float sum[NB] = {0};
+  for (int i = 0; i < NB - 1; ++i) {
+    int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
+    for (int j = 0; j < band_size; ++j) {
+      float frac = (float)j / band_size;
+      int idx = (eband5ms[i] << 2) + j;
+      float tmp = X[idx].r * P[idx].r + X[idx].i * P[idx].i;
+      sum[i] += (1 - frac) * tmp;
+      sum[i + 1] += frac * tmp;
+    }
+  }
+  sum[0] *= 2;
+  sum[NB - 1] *= 2;
+  memcpy(bandE, sum, sizeof sum);
+}
+
+static void interp_band_gain(float *g /*FREQ*/, const float *bandE) {
+  memset(g, 0, sizeof(float) * FREQ);
+  for (int i = 0; i < NB - 1; ++i) {
+    int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
+    for (int j = 0; j < band_size; ++j) {
+      float frac = (float)j / band_size;
+      g[(eband5ms[i] << 2) + j] = (1 - frac) * bandE[i] + frac * bandE[i + 1];
+    }
+  }
+}
+
+static void dct(float *out, const float *in) {
+  for (int i = 0; i < NB; ++i) {
+    float sum = 0;
+    for (int j = 0; j < NB; ++j) sum += in[j] * dct_table[j * NB + i];
+    out[i] = sum * sqrtf(2.0f / 22);
+  }
+}
+
+/* ------------------------------------------------------------ pitch tools */
+static float inner_prod(const float *x, const float *y, int n) {
+  float s = 0;
+  for (int i = 0; i < n; ++i) s += x[i] * y[i];
+  return s;
+}
+
+static void pitch_xcorr(const float *x, const float *y, float *xcorr, int len, int max_pitch) {
+  for (int i = 0; i < max_pitch; ++i) xcorr[i] = inner_prod(x, y + i, len);
+}
+
+static void celt_lpc4(float *lpc, const float *ac) {
+  const int p = 4;
+  float error = ac[0];
+  for (int i = 0; i < p; ++i) lpc[i] = 0;
+  if (ac[0] != 0) {
+    for (int i = 0; i < p; ++i) {
+      float rr = 0;
+      for (int j = 0; j < i; ++j) rr += lpc[j] * ac[i - j];
+      rr += ac[i + 1];
+      float r = -rr / error;
+      lpc[i] = r;
+      for (int j = 0; j < (i + 1) >> 1; ++j) {
+        float t1 = lpc[j], t2 = lpc[i - 1 - j];
+        lpc[j] = t1 + r * t2;
+        lpc[i - 1 - j] = t2 + r * t1;
+      }
+      error = error - r * r * error;
+      if (error < .001f * ac[0]) break;
+    }
+  }
+}
+
+static void pitch_downsample(const float *x, float *x_lp, int len) {
+  int half = len >> 1;
+  for (int i = 1; i < half; ++i) x_lp[i] = .5f * (.5f * (x[2 * i - 1] + x[2 * i + 1]) + x[2 * i]);
+  x_lp[0] = .5f * (.5f * x[1] + x[0]);
+  float ac[5];
+  for (int k = 0; k <= 4; ++k) {
+    float d = 0;
+    for (int i = k; i < half; ++i) d += x_lp[i] * x_lp[i - k];
+    ac[k] = d;
+  }
+  ac[0] *= 1.0001f;
+  for (int i = 1; i <= 4; ++i) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+  float lpc[4];
+  celt_lpc4(lpc, ac);
+  float tmp = 1.0f;
+  for (int i = 0; i < 4; ++i) {
+    tmp = .9f * tmp;
+    lpc[i] = lpc[i] * tmp;
+  }
+  const float c1 = .8f;
+  float n0 = lpc[0] + .8f, n1 = lpc[1] + c1 * lpc[0], n2 = lpc[2] + c1 * lpc[1], n3 = lpc[3] + c1 * lpc[2],
+        n4 = c1 * lpc[3];
+  float m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+  for (int i = 0; i < half; ++i) {
+    float sum = x_lp[i];
+    sum += n0 * m0;
+    sum += n1 * m1;
+    sum += n2 * m2;
+    sum += n3 * m3;
+    sum += n4 * m4;
+    m4 = m3; m3 = m2; m2 = m1; m1 = m0; m0 = x_lp[i];
+    x_lp[i] = sum;
+  }
+}
+
+static void find_best_pitch(const float *xcorr, const float *y, int len, int max_pitch, int *best_pitch) {
+  float Syy = 1;
+  float best_num[2] = {-1, -1}, best_den[2] = {0, 0};
+  best_pitch[0] = 0;
+  best_pitch[1] = 1;
+  for (int j = 0; j < len; ++j) Syy += y[j] * y[j];
+  for (int i = 0; i < max_pitch; ++i) {
+    if (xcorr[i] > 0) {
+      float xcorr16 = xcorr[i] * 1e-12f;
+      float num = xcorr16 * xcorr16;
+      if (num * best_den[1] > best_num[1] * Syy) {
+        if (num * best_den[0] > best_num[0] * Syy) {
+          best_num[1] = best_num[0]; best_den[1] = best_den[0]; best_pitch[1] = best_pitch[0];
+          best_num[0] = num; best_den[0] = Syy; best_pitch[0] = i;
+        } else {
+          best_num[1] = num; best_den[1] = Syy; best_pitch[1] = i;
+        }
+      }
+    }
+    Syy += y[i + len] * y[i + len] - y[i] * y[i];
+    Syy = fmaxf(1, Syy);
+  }
+}
+
+static void pitch_search(const float *x_lp, const float *y, int len, int max_pitch, int *pitch) {
+  int lag = len + max_pitch;
+  float x_lp4[PFRAME >> 2], y_lp4[(PFRAME + PMAX) >> 2], xcorr[PMAX >> 1];
+  int best_pitch[2] = {0, 0};
+  for (int j = 0; j < len >> 2; ++j) x_lp4[j] = x_lp[2 * j];
+  for (int j = 0; j < lag >> 2; ++j) y_lp4[j] = y[2 * j];
+  pitch_xcorr(x_lp4, y_lp4, xcorr, len >> 2, max_pitch >> 2);
+  find_best_pitch(xcorr, y_lp4, len >> 2, max_pitch >> 2, best_pitch);
+  for (int i = 0; i < max_pitch >> 1; ++i) {
+    xcorr[i] = 0;
+    if (abs(i - 2 * best_pitch[0]) > 2 && abs(i - 2 * best_pitch[1]) > 2) continue;
+    float sum = inner_prod(x_lp, y + i, len >> 1);
+    xcorr[i] = fmaxf(-1, sum);
+  }
+  find_best_pitch(xcorr, y, len >> 1, max_pitch >> 1, best_pitch);
+  int offset = 0;
+  if (best_pitch[0] > 0 && best_pitch[0] < (max_pitch >> 1) - 1) {
+    float a = xcorr[best_pitch[0] - 1], b = xcorr[best_pitch[0]], c = xcorr[best_pitch[0] + 1];
+    if ((c - a) > .7f * (b - a)) offset = 1;
+    else if ((a - c) > .7f * (b - c)) offset = -1;
+  }
+  *pitch = 2 * best_pitch[0] - offset;
+}
+
+static float compute_pitch_gain(float xy, float xx, float yy) { return xy / sqrtf(1 + xx * yy); }
+
+static const int second_check[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
+
+static float remove_doubling(const float *x, int maxperiod, int minperiod, int N, int *T0_, int prev_period,
+                             float prev_gain) {
+  int minperiod0 = minperiod;
+  maxperiod /= 2; minperiod /= 2; *T0_ /= 2; prev_period /= 2; N /= 2;
+  x += maxperiod;
+  if (*T0_ >= maxperiod) *T0_ = maxperiod - 1;
+  int T, T0;
+  T = T0 = *T0_;
+  float yy_lookup[(PMAX >> 1) + 1];
+  float xx = inner_prod(x, x, N), xy = inner_prod(x, x - T0, N);
+  yy_lookup[0] = xx;
+  float yy = xx;
+  for (int i = 1; i <= maxperiod; ++i) {
+    yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
+    yy_lookup[i] = fmaxf(0, yy);
+  }
+  yy = yy_lookup[T0];
+  float best_xy = xy, best_yy = yy;
+  float g, g0;
+  g = g0 = compute_pitch_gain(xy, xx, yy);
+  for (int k = 2; k <= 15; ++k) {
+    int T1 = (2 * T0 + k) / (2 * k);
+    if (T1 < minperiod) break;
+    int T1b;
+    if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+    else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
+    float xy1 = inner_prod(x, x - T1, N), xy2 = inner_prod(x, x - T1b, N);
+    xy = .5f * (xy1 + xy2);
+    yy = .5f * (yy_lookup[T1] + yy_lookup[T1b]);
+    float g1 = compute_pitch_gain(xy, xx, yy);
+    float cont;
+    if (abs(T1 - prev_period) <= 1) cont = prev_gain;
+    else if (abs(T1 - prev_period) <= 2 && 5 * k * k < T0) cont = .5f * prev_gain;
+    else cont = 0;
+    float thresh = fmaxf(.3f, .7f * g0 - cont);
+    if (T1 < 3 * minperiod) thresh = fmaxf(.4f, .85f * g0 - cont);
+    else if (T1 < 2 * minperiod) thresh = fmaxf(.5f, .9f * g0 - cont);
+    if (g1 > thresh) { best_xy = xy; best_yy = yy; T = T1; g = g1; }
+  }
+  best_xy = fmaxf(0, best_xy);
+  float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1);
+  float xc[3];
+  for (int k = 0; k < 3; ++k) xc[k] = inner_prod(x, x - (T + k - 1), N);
+  int offset = 0;
+  if ((xc[2] - xc[0]) > .7f * (xc[1] - xc[0])) offset = 1;
+  else if ((xc[0] - xc[2]) > .7f * (xc[1] - xc[2])) offset = -1;
+  if (pg > g) pg = g;
+  *T0_ = 2 * T + offset;
+  if (*T0_ < minperiod0) *T0_ = minperiod0;
+  return pg;
+}
+
+/* ------------------------------------------------------------------- RNN
+ * Accumulations are explicit fmaf chains in index order (bias, inputs, recurrent inputs): the
+ * GPU evaluates the same layers on the f32 matrix cores, whose result is exactly that chain. */
+#define WEIGHTS_SCALE (1.f / 256)
+
+static float tansig_approx(float x) {
+  if (!(x < 8)) return 1;
+  if (!(x > -8)) return -1;
+  float sign = 1;
+  if (x < 0) { x = -x; sign = -1; }
+  int i = (int)floorf(.5f + 25 * x);
+  x -= .04f * i;
+  float y = tansig_table[i];
+  float dy = 1 - y * y;
+  y = y + x * dy * (1 - y * x);
+  return sign * y;
+}
+static float sigmoid_approx(float x) { return .5f + .5f * tansig_approx(.5f * x); }
+
+static void dense(const int8_t *w, const int8_t *bias, int n_in, int n_out, int act, float *out, const float *in) {
+  for (int i = 0; i < n_out; ++i) {
+    float sum = bias[i];
+    for (int j = 0; j < n_in; ++j) sum = fmaf((float)w[j * n_out + i], in[j], sum);
+    sum = WEIGHTS_SCALE * sum;
+    out[i] = act == 0 ? tansig_approx(sum) : sigmoid_approx(sum);
+  }
+}
+
+static void gru(const int8_t *w, const int8_t *u, const int8_t *bias, int M, int N, float *state, const float *in) {
+  float z[96], r[96], h[96];
+  const int stride = 3 * N;
+  for (int i = 0; i < N; ++i) {
+    float sum = bias[i];
+    for (int j = 0; j < M; ++j) sum = fmaf((float)w[j * stride + i], in[j], sum);
+    for (int j = 0; j < N; ++j) sum = fmaf((float)u[j * stride + i], state[j], sum);
+    z[i] = sigmoid_approx(WEIGHTS_SCALE * sum);
+  }
+  for (int i = 0; i < N; ++i) {
+    float sum = bias[N + i];
+    for (int j = 0; j < M; ++j) sum = fmaf((float)w[N + i + j * stride], in[j], sum);
+    for (int j = 0; j < N; ++j) sum = fmaf((float)u[N + i + j * stride], state[j], sum);
+    r[i] = sigmoid_approx(WEIGHTS_SCALE * sum);
+  }
+  for (int i = 0; i < N; ++i) {
+    float sum = bias[2 * N + i];
+    for (int j = 0; j < M; ++j) sum = fmaf((float)w[2 * N + i + j * stride], in[j], sum);
+    for (int j = 0; j < N; ++j) sum = fmaf((float)u[2 * N + i + j * stride], state[j] * r[j], sum);
+    sum = WEIGHTS_SCALE * sum;
+    sum = sum < 0 ? 0 : sum; /* ReLU */
+    h[i] = z[i] * state[i] + (1 - z[i]) * sum;
+  }
+  memcpy(state, h, sizeof(float) * N);
+}
+
+/* splitmix-style generator -> small int8 weights, identical on every platform */
+static uint64_t wrng(uint64_t *s) {
+  uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static void fill_i8(int8_t *dst, size_t n, uint64_t *s, int amp) {
+  for (size_t i = 0; i < n; ++i) {
+    int a = (int)(wrng(s) % (2 * amp + 1)) - amp;
+    int b = (int)(wrng(s) % (2 * amp + 1)) - amp;
+    dst[i] = (int8_t)((a + b) / 2);
+  }
+}
+
+void afo_rnn_weights_synthetic(afo_rnn_weights *w, uint64_t seed) {
+  uint64_t s = seed;
+  fill_i8(w->input_dense_w, sizeof w->input_dense_w, &s, 48);
+  fill_i8(w->input_dense_b, sizeof w->input_dense_b, &s, 20);
+  fill_i8(w->vad_gru_w, sizeof w->vad_gru_w, &s, 40);
+  fill_i8(w->vad_gru_u, sizeof w->vad_gru_u, &s, 40);
+  fill_i8(w->vad_gru_b, sizeof w->vad_gru_b, &s, 20);
+  fill_i8(w->vad_out_w, sizeof w->vad_out_w, &s, 60);
+  fill_i8(w->vad_out_b, sizeof w->vad_out_b, &s, 20);
+  fill_i8(w->noise_gru_w, sizeof w->noise_gru_w, &s, 30);
+  fill_i8(w->noise_gru_u, sizeof w->noise_gru_u, &s, 30);
+  fill_i8(w->noise_gru_b, sizeof w->noise_gru_b, &s, 20);
+  fill_i8(w->denoise_gru_w, sizeof w->denoise_gru_w, &s, 24);
+  fill_i8(w->denoise_gru_u, sizeof w->denoise_gru_u, &s, 24);
+  fill_i8(w->denoise_gru_b, sizeof w->denoise_gru_b, &s, 20);
+  fill_i8(w->denoise_out_w, sizeof w->denoise_out_w, &s, 60);
+  fill_i8(w->denoise_out_b, sizeof w->denoise_out_b, &s, 40);
+}
+
+static void compute_rnn(const afo_rnn_weights *w, afo_rnn_state *st, float *gains, float *vad, const float *feat) {
+  float dense_out[24], noise_in[90], denoise_in[114];
+  dense(w->input_dense_w, w->input_dense_b, 42, 24, 0, dense_out, feat);
+  gru(w->vad_gru_w, w->vad_gru_u, w->vad_gru_b, 24, 24, st->vad_gru_state, dense_out);
+  dense(w->vad_out_w, w->vad_out_b, 24, 1, 1, vad, st->vad_gru_state);
+  memcpy(noise_in, dense_out, sizeof(float) * 24);
+  memcpy(noise_in + 24, st->vad_gru_state, sizeof(float) * 24);
+  memcpy(noise_in + 48, feat, sizeof(float) * 42);
+  gru(w->noise_gru_w, w->noise_gru_u, w->noise_gru_b, 90, 48, st->noise_gru_state, noise_in);
+  memcpy(denoise_in, st->vad_gru_state, sizeof(float) * 24);
+  memcpy(denoise_in + 24, st->noise_gru_state, sizeof(float) * 48);
+  memcpy(denoise_in + 72, feat, sizeof(float) * 42);
+  gru(w->denoise_gru_w, w->denoise_gru_u, w->denoise_gru_b, 114, 96, st->denoise_gru_state, denoise_in);
+  dense(w->denoise_out_w, w->denoise_out_b, 96, 22, 1, gains, st->denoise_gru_state);
+}
+
+/* debug tap of the last processed frame (tests compare GPU intermediates against it) */
+afo_rnn_debug afo_rnn_last;
+
+/* --------------------------------------------------------- DenoiseState */
+void afo_rnn_state_init(afo_rnn_state *st) {
+  init_tables();
+  memset(st, 0, sizeof(*st));
+}
+
+static void biquad_hp(float *y, float *mem, const float *x, int n) {
+  const float b0 = -2.0f, b1 = 1.0f, a0 = -1.99599f, a1 = 0.99600f;
+  for (int i = 0; i < n; ++i) {
+    float xi = x[i];
+    float yi = x[i] + mem[0];
+    mem[0] = mem[1] + (b0 * xi - a0 * yi);
+    mem[1] = (b1 * xi - a1 * yi);
+    y[i] = yi;
+  }
+}
+
+static void pitch_filter(cpx *X, const cpx *P, const float *Ex, const float *Ep, const float *Exp, const float *g) {
+  float r[NB], rf[FREQ], newE[NB], norm[NB], normf[FREQ];
+  for (int i = 0; i < NB; ++i) {
+    if (Exp[i] > g[i]) r[i] = 1;
+    else r[i] = Exp[i] * Exp[i] * (1 - g[i] * g[i]) / (.001f + g[i] * g[i] * (1 - Exp[i] * Exp[i]));
+    r[i] = sqrtf(fminf(1, fmaxf(0, r[i])));
+    r[i] *= sqrtf(Ex[i] / (1e-8f + Ep[i]));
+  }
+  interp_band_gain(rf, r);
+  for (int i = 0; i < FREQ; ++i) {
+    X[i].r += rf[i] * P[i].r;
+    X[i].i += rf[i] * P[i].i;
+  }
+  compute_band_energy(newE, X);
+  for (int i = 0; i < NB; ++i) norm[i] = sqrtf(Ex[i] / (1e-8f + newE[i]));
+  interp_band_gain(normf, norm);
+  for (int i = 0; i < FREQ; ++i) {
+    X[i].r *= normf[i];
+    X[i].i *= normf[i];
+  }
+}
+
+float afo_rnn_process_frame(const afo_rnn_weights *w, afo_rnn_state *st, float *out, const float *in) {
+  float x[FRAME], buf[WINDOW];
+  cpx X[FREQ], P[FREQ];
+  float Ex[NB], Ep[NB], Exp[NB], features[NFEAT], g[NB], gf[FREQ], Ly[NB], tmp[NB];
+  float vad_prob = 0;
+  biquad_hp(x, st->mem_hp_x, in, FRAME);
+  /* frame_analysis */
+  memcpy(buf, st->analysis_mem, sizeof(float) * FRAME);
+  memcpy(buf + FRAME, x, sizeof(float) * FRAME);
+  memcpy(st->analysis_mem, x, sizeof(float) * FRAME);
+  apply_window(buf);
+  forward_transform(X, buf);
+  compute_band_energy(Ex, X);
+  for (int i = 0; i < FREQ; ++i) { afo_rnn_last.X[2 * i] = X[i].r; afo_rnn_last.X[2 * i + 1] = X[i].i; }
+  /* pitch */
+  memmove(st->pitch_buf, st->pitch_buf + FRAME, sizeof(float) * (PBUF - FRAME));
+  memcpy(st->pitch_buf + PBUF - FRAME, x, sizeof(float) * FRAME);
+  float pitch_ds[PBUF >> 1];
+  pitch_downsample(st->pitch_buf, pitch_ds, PBUF);
+  int pitch_index;
+  pitch_search(pitch_ds + (PMAX >> 1), pitch_ds, PFRAME, PMAX - 3 * PMIN, &pitch_index);
+  pitch_index = PMAX - pitch_index;
+  float gain = remove_doubling(pitch_ds, PMAX, PMIN, PFRAME, &pitch_index, st->last_period, st->last_gain);
+  st->last_period = pitch_index;
+  st->last_gain = gain;
+  for (int i = 0; i < WINDOW; ++i) buf[i] = st->pitch_buf[PBUF - WINDOW - pitch_index + i];
+  apply_window(buf);
+  forward_transform(P, buf);
+  for (int i = 0; i < FREQ; ++i) { afo_rnn_last.P[2 * i] = P[i].r; afo_rnn_last.P[2 * i + 1] = P[i].i; }
+  compute_band_energy(Ep, P);
+  compute_band_corr(Exp, X, P);
+  for (int i = 0; i < NB; ++i) Exp[i] = Exp[i] / sqrtf(.001f + Ex[i] * Ep[i]);
+  dct(tmp, Exp);
+  for (int i = 0; i < NDELTA; ++i) features[NB + 2 * NDELTA + i] = tmp[i];
+  features[NB + 2 * NDELTA] -= 1.3f;
+  features[NB + 2 * NDELTA + 1] -= 0.9f;
+  features[NB + 3 * NDELTA] = .01f * (pitch_index - 300);
+  float logMax = -2, follow = -2, E = 0;
+  for (int i = 0; i < NB; ++i) {
+    Ly[i] = log10f(1e-2f + Ex[i]);
+    Ly[i] = fmaxf(logMax - 7, fmaxf(follow - 1.5f, Ly[i]));
+    logMax = fmaxf(logMax, Ly[i]);
+    follow = fmaxf(follow - 1.5f, Ly[i]);
+    E += Ex[i];
+  }
+  int silence = 0;
+  if (E < 0.04f) {
+    memset(features, 0, sizeof features);
+    silence = 1;
+  } else {
+    dct(features, Ly);
+    features[0] -= 12;
+    features[1] -= 4;
+    float *ceps_0 = st->cepstral_mem[st->memid];
+    float *ceps_1 = (st->memid < 1) ? st->cepstral_mem[CEPS_MEM + st->memid - 1] : st->cepstral_mem[st->memid - 1];
+    float *ceps_2 = (st->memid < 2) ? st->cepstral_mem[CEPS_MEM + st->memid - 2] : st->cepstral_mem[st->memid - 2];
+    for (int i = 0; i < NB; ++i) ceps_0[i] = features[i];
+    st->memid++;
+    for (int i = 0; i < NDELTA; ++i) {
+      features[i] = ceps_0[i] + ceps_1[i] + ceps_2[i];
+      features[NB + i] = ceps_0[i] - ceps_2[i];
+      features[NB + NDELTA + i] = ceps_0[i] - 2 * ceps_1[i] + ceps_2[i];
+    }
+    if (st->memid == CEPS_MEM) st->memid = 0;
+    float spec_variability = 0;
+    for (int i = 0; i < CEPS_MEM; ++i) {
+      float mindist = 1e15f;
+      for (int j = 0; j < CEPS_MEM; ++j) {
+        float dist = 0;
+        for (int k = 0; k < NB; ++k) {
+          float t = st->cepstral_mem[i][k] - st->cepstral_mem[j][k];
+          dist += t * t;
+        }
+        if (j != i) mindist = fminf(mindist, dist);
+      }
+      spec_variability += mindist;
+    }
+    features[NB + 3 * NDELTA + 1] = spec_variability / CEPS_MEM - 2.1f;
+  }
+  if (!silence) {
+    compute_rnn(w, st, g, &vad_prob, features);
+    pitch_filter(X, P, Ex, Ep, Exp, g);
+    for (int i = 0; i < NB; ++i) {
+      g[i] = fmaxf(g[i], 0.6f * st->lastg[i]);
+      st->lastg[i] = g[i];
+    }
+    interp_band_gain(gf, g);
+    for (int i = 0; i < FREQ; ++i) {
+      X[i].r *= gf[i];
+      X[i].i *= gf[i];
+    }
+  }
+  memcpy(afo_rnn_last.Ex, Ex, sizeof Ex);
+  memcpy(afo_rnn_last.Ep, Ep, sizeof Ep);
+  memcpy(afo_rnn_last.Exp, Exp, sizeof Exp);
+  memcpy(afo_rnn_last.features, features, sizeof features);
+  memcpy(afo_rnn_last.gains, g, sizeof g);
+  afo_rnn_last.pitch_index = pitch_index;
+  afo_rnn_last.pitch_gain = gain;
+  afo_rnn_last.silence = silence;
+  /* frame_synthesis */
+  inverse_transform(buf, X);
+  apply_window(buf);
+  for (int i = 0; i < FRAME; ++i) out[i] = buf[i] + st->synthesis_mem[i];
+  memcpy(st->synthesis_mem, buf + FRAME, sizeof(float) * FRAME);
+  return vad_prob;
+}
+
+/* ------------------------------------------- wrapper: dsp/rnnoise.rs:45-164 */
+void afo_suppressor_init(afo_suppressor *s, float strength, uint64_t weight_seed) {
+  memset(s, 0, sizeof(*s));
+  afo_rnn_state_init(&s->st);
+  afo_rnn_weights_synthetic(&s->w, weight_seed);
+  const float sample_rate = 48000.0f, smoothing_ms = 15.0f;
+  const float tau = smoothing_ms / 1000.0f;
+  const float frame_dt = (float)FRAME / sample_rate;
+  s->smoothing_coeff = 1.0f - expf(-(frame_dt / tau)); /* rnnoise.rs:45-51 */
+  s->smoothed_strength = 1.0f;
+  s->strength = strength < 0 ? 0 : (strength > 1 ? 1 : strength);
+}
+
+/* rnnoise.rs:89-111 */
+static float scale_sample_for_model(float sample) {
+  const float PCM_SCALE = 32768.0f, LIMIT = 32760.0f, LIMIT_UNIT = 32760.0f / 32768.0f, THR = 0.98f;
+  const float KNEE = 1.0f - 0.98f;
+  float v;
+  if (!isfinite(sample)) v = 0.0f;
+  else {
+    float sign = sample > 0 ? 1.0f : (sample < 0 ? -1.0f : (signbit(sample) ? -1.0f : 1.0f));
+    float magnitude = fabsf(sample);
+    if (magnitude <= THR) v = sample;
+    else {
+      float over = magnitude - THR;
+      float compressed = over / (over + KNEE);
+      float softened = THR + (LIMIT_UNIT - THR) * compressed;
+      v = sign * fminf(softened, LIMIT_UNIT);
+    }
+  }
+  float scaled = v * PCM_SCALE;
+  return scaled < -LIMIT ? -LIMIT : (scaled > LIMIT ? LIMIT : scaled);
+}
+
+/* one 480-sample frame of RNNoiseProcessor::process_frames (rnnoise.rs:122-164) */
+void afo_suppressor_process_frame(afo_suppressor *s, float *out, const float *dry) {
+  float scaled[FRAME], wet[FRAME];
+  for (int i = 0; i < FRAME; ++i) scaled[i] = scale_sample_for_model(dry[i]);
+  afo_rnn_process_frame(&s->w, &s->st, wet, scaled);
+  for (int i = 0; i < FRAME; ++i) wet[i] /= 32768.0f;
+  s->smoothed_strength = s->strength * s->smoothing_coeff + s->smoothed_strength * (1.0f - s->smoothing_coeff);
+  float strength = s->smoothed_strength;
+  if (strength < 1.0f) {
+    for (int i = 0; i < FRAME; ++i) wet[i] = (strength * wet[i]) + ((1.0f - strength) * dry[i]);
+  }
+  memcpy(out, wet, sizeof(float) * FRAME);
+}
+
+/* whole clip in complete frames (the tail shorter than a frame stays buffered, like the ring) */
+size_t afo_suppressor_process(afo_suppressor *s, float *out, const float *in, size_t n) {
+  size_t frames = n / FRAME;
+  for (size_t f = 0; f < frames; ++f) afo_suppressor_process_frame(s, out + f * FRAME, in + f * FRAME);
+  return frames * FRAME;
+}
+
+/* bin/rnnoise_benchmark.rs:51-117 file protocol core: clamp(+-1)*32768 -> process_frame -> /32768 */
+void afo_rnnoise_benchmark_frames(const float *in, float *out, size_t n, uint64_t weight_seed) {
+  afo_rnn_weights w;
+  afo_rnn_state st;
+  afo_rnn_weights_synthetic(&w, weight_seed);
+  afo_rnn_state_init(&st);
+  float frame_in[FRAME], frame_out[FRAME];
+  for (size_t start = 0; start < n; start += FRAME) {
+    size_t len = n - start < FRAME ? n - start : FRAME;
+    memset(frame_in, 0, sizeof frame_in);
+    for (size_t i = 0; i < len; ++i) {
+      float v = in[start + i];
+      v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+      frame_in[i] = v * 32768.0f;
+    }
+    afo_rnn_process_frame(&w, &st, frame_out, frame_in);
+    for (size_t i = 0; i < len; ++i) out[start + i] = frame_out[i] / 32768.0f;
+  }
+}
