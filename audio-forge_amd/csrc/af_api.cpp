@@ -84,7 +84,7 @@ struct af_engine {
   hipStream_t last_stream = nullptr;
   af::SuppressorHost supp;
   int supp_window_frames = 50;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
   af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}
 };
@@ -290,6 +290,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_io);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
   }
   if (e->supp.d_blob || e->supp.d_state || e->supp.d_xh) {
     (void)hipSetDevice(e->device);
@@ -519,6 +520,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (!e->ev_start) {
       AF_HIP(hipEventCreate(&e->ev_start));
       AF_HIP(hipEventCreate(&e->ev_stop));
+      AF_HIP(hipEventCreate(&e->ev_mid));
     }
     AF_HIP(hipEventRecord(e->ev_start, stream));
   }
@@ -587,6 +589,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     chain_in = out;
   }
+  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, stream));
 
   const bool ring_fits = af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   const bool auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
@@ -708,6 +711,20 @@ int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches) {
   float t = 0.0f;
   AF_HIP(hipEventElapsedTime(&t, e->ev_start, e->ev_stop));
   *ms = (double)t;
+  return AF_OK;
+}
+
+int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_ms) {
+  if (!e || !suppressor_ms || !chain_ms) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  *suppressor_ms = *chain_ms = 0.0;
+  if (!e->timing || !e->ev_start || e->last_launches == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipEventSynchronize(e->ev_stop));
+  float t = 0.0f;
+  AF_HIP(hipEventElapsedTime(&t, e->ev_start, e->ev_mid));
+  *suppressor_ms = (double)t;
+  AF_HIP(hipEventElapsedTime(&t, e->ev_mid, e->ev_stop));
+  *chain_ms = (double)t;
   return AF_OK;
 }
 

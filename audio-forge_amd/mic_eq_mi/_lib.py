@@ -126,6 +126,7 @@ SIGNATURES = {
     "af_engine_set_ring_variant": (C.c_int, [_vp, _i32, _i32]),
     "af_engine_set_timing_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(_i32)]),
+    "af_engine_last_stage_ms": (C.c_int, [_vp, _dp, _dp]),
     "af_eq_magnitude_response": (C.c_int, [_dp, _sz, _dp, _d, _dp]),
     "af_eq_magnitude_response_v2": (C.c_int, [_dp, _sz, C.POINTER(EqBandConfig), _d, _dp]),
     "af_engine_eq_magnitude_response": (C.c_int, [_vp, _dp, _sz, _dp]),

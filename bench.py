@@ -77,7 +77,7 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
     return out
 
 
-def cpu_baseline(seconds: float, budget_s: float = 15.0) -> dict:
+def cpu_baseline(seconds: float, full: bool, budget_s: float = 15.0) -> dict:
     """The oracle (CPU restatement of rust-core; the Rust reference cannot be built here) on 1 host thread."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import af_oracle_py as oracle  # the checker / baseline, never the product path
@@ -93,7 +93,12 @@ def cpu_baseline(seconds: float, budget_s: float = 15.0) -> dict:
         st, f0, ph = stream_params(streams)
         x = kat_signal(n_blocks, st, f0, ph)
         t0 = time.perf_counter()
-        oracle.simulate_auto_eq_chain(x, SAMPLE_RATE, BANDS, settings)
+        if full:
+            y = oracle.prefilter(x)
+            y = oracle.suppressor_process(y, 1.0, 0x5EED)
+            oracle.simulate_auto_eq_chain(y, SAMPLE_RATE, BANDS, settings)
+        else:
+            oracle.simulate_auto_eq_chain(x, SAMPLE_RATE, BANDS, settings)
         elapsed += time.perf_counter() - t0
         frames += x.size
         streams += 1
@@ -107,7 +112,8 @@ def cpu_baseline(seconds: float, budget_s: float = 15.0) -> dict:
         pass
     return {
         "value": frames / elapsed, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{streams} streams x {seconds:g} s of the same S3 workload, same chain settings, 1 thread",
+        "sample": f"{streams} streams x {seconds:g} s of the same S3 workload, same chain ({'full' if full else 'dynamics'}), 1 thread; "
+                  "the RNNoise stage of this port uses a plain mixed-radix FFT (the reference crate measures 40.9 us/frame, BASELINE.md)",
         "x_realtime": frames / elapsed / SAMPLE_RATE, "host_cpu": cpu_model, "host_cores": os.cpu_count(),
     }
 
@@ -122,6 +128,9 @@ def main() -> None:
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--variant", type=str, default="", help="lane | ring-<waves>x<chunk> (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain", choices=["full", "dynamics"], default="full",
+                    help="full = DC/HP prefilter + RNNoise + EQ + compressor + limiter + true-peak (configs[2]); "
+                         "dynamics = EQ + compressor + limiter + true-peak only (configs[1] chain)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,6 +168,10 @@ def main() -> None:
     core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, CHAIN_SETTINGS)
     if not args.variant:
         engine.set_kernel(args.kernel)
+    full = args.chain == "full"
+    if full:
+        engine.set_prefilter_enabled(1, 1)   # DC block + 80 Hz high-pass, routing.rs:826-843
+        engine.set_suppressor_enabled(1)     # RNNoise, rnnoise.rs:122-164 (synthetic weights: trained ones are not offline)
     engine.set_timing_enabled(1)
     hip_stream = torch.cuda.current_stream().cuda_stream
 
@@ -173,11 +186,15 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
+    kernel_ms, supp_ms, chain_ms = [], [], []
+    sm, cm = C.c_double(0.0), C.c_double(0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         kernel_ms.append(engine.last_kernel_ms()[0])  # waits on this step's stop event only
+        engine._lib.af_engine_last_stage_ms(engine._h, C.byref(sm), C.byref(cm))
+        supp_ms.append(sm.value)
+        chain_ms.append(cm.value)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -196,7 +213,8 @@ def main() -> None:
 
     kernel_name = "chain_lane_kernel" if args.variant == "lane" or args.kernel == 1 else "chain_ring_kernel<" + (args.variant[5:] if args.variant.startswith("ring-") else "16x4") + ">"
     if rank == 0:
-        avg_kernel_s = float(np.mean(kernel_ms)) / 1000.0
+        # dominant kernel: the chain launch (HIP events recorded by the engine around it on this stream)
+        avg_kernel_s = float(np.mean(chain_ms)) / 1000.0
         frames_per_launch = streams * n
         achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         line = {
@@ -214,8 +232,11 @@ def main() -> None:
             "data": "synthetic",
             "x_realtime": value / SAMPLE_RATE,
             "config": {
-                "workload": f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, 10-band EQ + compressor + 2 ms lookahead "
-                            f"limiter + 4x true-peak limiter/detector (BASELINE configs[2] shape; RNNoise stage not built yet)",
+                "workload": (f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, full chain: DC block + 80 Hz HP -> RNNoise "
+                             f"suppressor (synthetic weights) -> 10-band EQ -> compressor -> 2 ms lookahead limiter -> 4x true-peak "
+                             f"limiter/detector (BASELINE configs[2])") if full else
+                            (f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, 10-band EQ + compressor + 2 ms lookahead "
+                             f"limiter + 4x true-peak limiter/detector, no suppressor (BASELINE configs[1] chain)"),
                 "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
                 "kernel": kernel_name, "sharding": f"streams x{world}, no data-path collective",
             },
@@ -225,11 +246,13 @@ def main() -> None:
                 "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0,
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
             },
+            "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),
+                         "all_kernels": float(np.mean(kernel_ms))},
             "checks": {"output_rms": float(np.sqrt(float(metrics_sum[0]) / (world * streams * n))),
                        "output_sample_peak": float(metrics_max[0]), "max_compressor_gr_db": float(metrics_max[2])},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.seconds)
+            line["cpu_baseline"] = cpu_baseline(args.seconds, full)
         print(json.dumps(line))
     engine.close()
     if distributed:

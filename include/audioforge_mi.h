@@ -217,6 +217,8 @@ int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk);
  * measured on the stream the kernels ran on (0 when timing is disabled) */
 int af_engine_set_timing_enabled(af_engine *e, int32_t enabled);
 int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches);
+/* the same split at the suppressor | chain boundary (front-end pre-pass counts as suppressor time) */
+int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_ms);
 
 /* ---- stateless helpers ----------------------------------------------------------- */
 /* eq_magnitude_response, lib.rs:99-150 (legacy (freq, gain_db, q) x 10 bands) */

@@ -398,3 +398,18 @@ def suppressor_process(audio, strength: float = 1.0, weight_seed: int = 0x5EED) 
     out = np.zeros_like(audio)
     n = lib().afo_suppressor_process(state, _fptr(out), _fptr(audio), audio.size)
     return out[:n]
+
+
+def prefilter(audio, sample_rate: float = 48000.0) -> np.ndarray:
+    """DC block + 80 Hz high-pass (routing.rs:826-843)."""
+    class Pre(C.Structure):
+        _fields_ = [("dc_x1", C.c_float), ("dc_y1", C.c_float), ("hp", C.c_byte * 256)]
+
+    L = lib()
+    L.afo_prefilter_init.argtypes = [C.c_void_p, C.c_double]
+    L.afo_prefilter_process_block.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int]
+    pre = Pre()
+    L.afo_prefilter_init(C.byref(pre), float(sample_rate))
+    out = np.ascontiguousarray(audio, dtype=np.float32).copy()
+    L.afo_prefilter_process_block(C.byref(pre), _fptr(out), out.size, 1)
+    return out
