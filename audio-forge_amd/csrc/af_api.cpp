@@ -540,28 +540,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
                   af::kRnnFrame);
     if (e->supp.weights_dirty) AF_HIP(e->supp.upload());
+    // the realtime front end (clamp + DC block + 80 Hz HP, routing.rs:802-843) runs inside the suppressor's
+    // own sample-serial pre-pass, so the chain launch afterwards must not repeat it
     const uint32_t front = af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
-    if (run.flags & front) {
-      // front end (clamp + DC block + 80 Hz HP) as its own launch so the suppressor sees filtered audio
-      const size_t need = af::ring_kernel_dynamic_lds(0, run.lim.lookahead_samples, false);
-      if (need > af::kMaxLdsBytes) return fail(AF_ERR_UNSUPPORTED, "front-end pre-pass does not fit in LDS");
-      af::ChainParams pre = run;
-      pre.flags = (pre.flags & (front | af::kFlagInputScrub)) | af::kFlagPrePass;
-      pre.n_eq_sections = run.n_eq_sections;
-      if (rows > e->stats_pre_capacity) {
-        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
-        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
-        e->stats_pre_capacity = rows;
-      }
-      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      af::LaunchArgs a0 = a;
-      a0.params = e->d_params_pre;
-      a0.in = chain_in;
-      a0.stats = e->d_stats_pre;
-      AF_HIP(af::launch_chain_ring(a0, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
-      e->last_launches += 1;
-      chain_in = out;
+    const uint32_t front_flags = run.flags & front;
+    if (front_flags) {
       run.flags &= ~(front | af::kFlagInputScrub);
       run_modified = true;
     }
@@ -584,6 +567,15 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       sa.strength = e->supp.strength;
       sa.smoothing_coeff = 1.0f - std::exp(-((480.0f / 48000.0f) / (15.0f / 1000.0f)));  // rnnoise.rs:45-51
       sa.raw_protocol = e->supp.raw_protocol ? 1 : 0;
+      sa.front_clamp = (front_flags & af::kFlagInputClamp) ? 1 : 0;
+      sa.front_dc = (front_flags & af::kFlagDcBlock) ? 1 : 0;
+      sa.front_hp = (front_flags & af::kFlagPreHighpass) ? 1 : 0;
+      sa.hp_b0 = run.pre_hp.b0; sa.hp_b1 = run.pre_hp.b1; sa.hp_b2 = run.pre_hp.b2;
+      sa.hp_a1 = run.pre_hp.a1; sa.hp_a2 = run.pre_hp.a2;
+      sa.chain_st64 = e->d_st64;
+      sa.chain_st32 = e->d_st32;
+      sa.f64_pre_z1 = af::kPreZ1;
+      sa.f32_dc_x1 = af::kDcX1;
       AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
       e->last_launches += 4;
     }

@@ -26,6 +26,7 @@
 //                          interpolation, inverse STFT, overlap-add, /32768, wet/dry mix.
 #include <hip/hip_runtime.h>
 
+#include "af_fft_consts.h"
 #include "af_suppressor.h"
 
 namespace af {
@@ -59,34 +60,66 @@ __device__ __forceinline__ float scale_for_model(float sample) {
 
 extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
   __shared__ float tile[64][65];
+  __shared__ float dry[64][65];
   const int lane = threadIdx.x;
   const int s0 = blockIdx.x * 64;
   const int s = s0 + lane;
   const bool valid = s < a.n_streams;
   const int sc = valid ? s : a.n_streams - 1;
+  const int64_t NS = a.n_streams;
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
   const int64_t xh_stride = kPitchBuf + n;
+  const bool front = a.front_clamp || a.front_dc;
   float *st = a.state + (int64_t)sc * SuppState::kCount;
   float m0 = st[SuppState::kHpMem], m1 = st[SuppState::kHpMem + 1];
+  // realtime front end state (chain planes): DC block x1/y1 (f32), 80 Hz high-pass z1/z2 (f64)
+  float dc_x1 = 0.0f, dc_y1 = 0.0f;
+  double z1 = 0.0, z2 = 0.0;
+  if (a.front_dc) {
+    dc_x1 = a.chain_st32[(int64_t)a.f32_dc_x1 * NS + sc];
+    dc_y1 = a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + sc];
+    z1 = a.chain_st64[(int64_t)a.f64_pre_z1 * NS + sc];
+    z2 = a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + sc];
+  }
   // history: the previous 1728 model-input samples go in front of the window
   for (int r = 0; r < 64; ++r) {
-    const int sr = s0 + r;
-    if (sr >= a.n_streams) break;
+    const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
+#pragma unroll 9
     for (int i = lane; i < kPitchBuf; i += 64)
       a.xh[(int64_t)sr * xh_stride + i] = a.state[(int64_t)sr * SuppState::kCount + SuppState::kHist + i];
   }
   const float b0 = -2.0f, b1 = 1.0f, a0 = -1.99599f, a1 = 0.99600f;  // RNNoise input high-pass
   for (int64_t t0 = 0; t0 < n; t0 += 64) {
+    // n is a multiple of 480, so every tile except possibly the last is full; rows are clamped, not skipped,
+    // so the 64 row loads of a tile are independent and stay in flight together
     const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
+    const int64_t col = a.frame0 * kRnnFrame + t0 + (lane < len ? lane : len - 1);
+#pragma unroll 16
     for (int r = 0; r < 64; ++r) {
-      const int sr = s0 + r;
-      float v = 0.0f;
-      if (sr < a.n_streams && lane < len) v = a.in[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + t0 + lane];
-      tile[lane][r] = v;
+      const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
+      tile[lane][r] = a.in[(int64_t)sr * a.stream_stride + col];
     }
     __syncthreads();
     for (int t = 0; t < len; ++t) {
       float x = tile[t][lane];
+      if (front) {
+        if (!finite32(x)) x = 0.0f;                                              // routing.rs:808-811
+        if (a.front_clamp) x = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);        // routing.rs:822
+        if (a.front_dc) {                                                        // routing.rs:832-840
+          const float o = x - dc_x1 + 0.995f * dc_y1;
+          dc_x1 = x;
+          dc_y1 = o;
+          x = o;
+          if (a.front_hp) {
+            const double xin = (double)o;
+            const double y = a.hp_b0 * xin + z1;
+            z1 = a.hp_b1 * xin - a.hp_a1 * y + z2;
+            z2 = a.hp_b2 * xin - a.hp_a2 * y;
+            x = (float)y;
+          }
+        }
+        dry[t][lane] = x;
+      }
       if (a.raw_protocol) {  // bin/rnnoise_benchmark.rs:75-79
         x = (x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x)) * 32768.0f;
       } else {
@@ -98,15 +131,26 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
       tile[t][lane] = y;
     }
     __syncthreads();
+#pragma unroll 16
     for (int r = 0; r < 64; ++r) {
       const int sr = s0 + r;
-      if (sr < a.n_streams && lane < len) a.xh[(int64_t)sr * xh_stride + kPitchBuf + t0 + lane] = tile[lane][r];
+      if (sr < a.n_streams && lane < len) {
+        a.xh[(int64_t)sr * xh_stride + kPitchBuf + t0 + lane] = tile[lane][r];
+        // the dry signal the wet/dry mix sees is the suppressor's input, i.e. the front end's output
+        if (front) a.out[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + t0 + lane] = dry[lane][r];
+      }
     }
     __syncthreads();
   }
   if (valid) {
     st[SuppState::kHpMem] = m0;
     st[SuppState::kHpMem + 1] = m1;
+    if (a.front_dc) {
+      a.chain_st32[(int64_t)a.f32_dc_x1 * NS + s] = dc_x1;
+      a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + s] = dc_y1;
+      a.chain_st64[(int64_t)a.f64_pre_z1 * NS + s] = z1;
+      a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + s] = z2;
+    }
   }
 }
 
@@ -116,7 +160,21 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
 // out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.  `a` is consumed; the result lands in `b`.
 __device__ __forceinline__ float2 cmul(float2 x, float2 w) { return make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x); }
 
-__device__ void fft960_wave(float2 *a, float2 *b, const float2 *tw, int lane, float scale) {
+// Per-lane twiddles are loop invariants of the whole kernel: W_960^(lane*k1) for the fifteen k1 and
+// W_64^(q*r) of the lane's radix-8 cell live in registers; W_15 and W_8 are literals.
+struct FftLane {
+  float2 tw960[15];
+  float2 tw64;
+};
+__device__ __forceinline__ FftLane fft_lane_init(const float2 *tw, int lane) {
+  FftLane f;
+#pragma unroll
+  for (int k1 = 0; k1 < 15; ++k1) f.tw960[k1] = tw[(lane * k1) % kRnnWindow];
+  f.tw64 = tw[(lane & 7) * (lane >> 3) * 15];
+  return f;
+}
+
+__device__ __forceinline__ void fft960_wave(float2 *a, float2 *b, const FftLane &fl, int lane, float scale) {
   float2 xin[15];
 #pragma unroll
   for (int n1 = 0; n1 < 15; ++n1) xin[n1] = a[64 * n1 + lane];
@@ -126,35 +184,43 @@ __device__ void fft960_wave(float2 *a, float2 *b, const float2 *tw, int lane, fl
     float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
     for (int n1 = 0; n1 < 15; ++n1) {
-      const float2 w = tw[((n1 * k1) % 15) * 64];
+      const float2 w = make_float2(kW15[(n1 * k1) % 15][0], kW15[(n1 * k1) % 15][1]);
       const float2 p = cmul(xin[n1], w);
       acc.x += p.x;
       acc.y += p.y;
     }
-    b[k1 * 64 + lane] = cmul(acc, tw[(lane * k1) % kRnnWindow]);
+    b[k1 * 64 + lane] = cmul(acc, fl.tw960[k1]);
   }
   __syncthreads();
   {
     const int q = lane & 7, r = lane >> 3;
+    float2 w8[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) w8[p] = make_float2(kW8[(p * r) & 7][0], kW8[(p * r) & 7][1]);
+#pragma unroll 3
     for (int k1 = 0; k1 < 15; ++k1) {
       float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const float2 v = cmul(b[k1 * 64 + 8 * p + q], tw[((p * r) & 7) * 120]);
+        const float2 v = cmul(b[k1 * 64 + 8 * p + q], w8[p]);
         acc.x += v.x;
         acc.y += v.y;
       }
-      a[k1 * 64 + q * 8 + r] = cmul(acc, tw[q * r * 15]);
+      a[k1 * 64 + q * 8 + r] = cmul(acc, fl.tw64);
     }
   }
   __syncthreads();
   {
     const int r = lane & 7, t = lane >> 3;
+    float2 w8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w8[q] = make_float2(kW8[(q * t) & 7][0], kW8[(q * t) & 7][1]);
+#pragma unroll 3
     for (int k1 = 0; k1 < 15; ++k1) {
       float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float2 v = cmul(a[k1 * 64 + q * 8 + r], tw[((q * t) & 7) * 120]);
+        const float2 v = cmul(a[k1 * 64 + q * 8 + r], w8[q]);
         acc.x += v.x;
         acc.y += v.y;
       }
@@ -165,25 +231,26 @@ __device__ void fft960_wave(float2 *a, float2 *b, const float2 *tw, int lane, fl
 }
 
 // compute_band_energy / compute_band_corr: lane b accumulates band b in the order the scalar code does
-// (first the rising half fed by band b-1's bins, then the falling half of its own bins)
-__device__ __forceinline__ float band_sum(const float2 *X, const float2 *Pm, int b) {
+// (first the rising half fed by band b-1's bins, then the falling half of its own bins).  `frac` holds
+// (float)j / (float)band_size per bin, evaluated once on the host (the same IEEE division).
+__device__ __forceinline__ float band_sum(const float2 *X, const float2 *Pm, const float *frac, int b) {
   float sum = 0.0f;
   if (b > 0) {
     const int e0 = c_eband[b - 1] << 2, size = (c_eband[b] - c_eband[b - 1]) << 2;
+#pragma unroll 4
     for (int j = 0; j < size; ++j) {
-      const float frac = (float)j / (float)size;
       const float2 x = X[e0 + j], p = Pm[e0 + j];
       const float tmp = x.x * p.x + x.y * p.y;
-      sum += frac * tmp;
+      sum += frac[e0 + j] * tmp;
     }
   }
   if (b < kRnnBands - 1) {
     const int e0 = c_eband[b] << 2, size = (c_eband[b + 1] - c_eband[b]) << 2;
+#pragma unroll 4
     for (int j = 0; j < size; ++j) {
-      const float frac = (float)j / (float)size;
       const float2 x = X[e0 + j], p = Pm[e0 + j];
       const float tmp = x.x * p.x + x.y * p.y;
-      sum += (1 - frac) * tmp;
+      sum += (1 - frac[e0 + j]) * tmp;
     }
   }
   if (b == 0 || b == kRnnBands - 1) sum *= 2;
@@ -191,19 +258,16 @@ __device__ __forceinline__ float band_sum(const float2 *X, const float2 *Pm, int
 }
 
 // interp_band_gain value at one bin
-__device__ __forceinline__ float interp_gain(const float *bandE, int bin) {
-  if (bin >= (c_eband[kRnnBands - 1] << 2)) return 0.0f;
-  int b = 0;
-#pragma unroll
-  for (int i = 1; i < kRnnBands; ++i) b += (bin >= (c_eband[i] << 2)) ? 1 : 0;
-  const int e0 = c_eband[b] << 2, size = (c_eband[b + 1] - c_eband[b]) << 2;
-  const float frac = (float)(bin - e0) / (float)size;
-  return (1 - frac) * bandE[b] + frac * bandE[b + 1];
+__device__ __forceinline__ float interp_gain(const float *bandE, const float *frac, const int32_t *band_of_bin, int bin) {
+  if (bin >= (100 << 2)) return 0.0f;
+  const int b = band_of_bin[bin];
+  const float f = frac[bin];
+  return (1 - f) * bandE[b] + f * bandE[b + 1];
 }
 
 // ============================================================================== analysis
 struct AnalysisLds {
-  float pbuf[kPitchBuf];
+  float frac[404];
   float ds[kPitchBuf / 2];
   float2 fa[kRnnWindow], fb[kRnnWindow];
   float2 X[kRnnFreq + 3];
@@ -230,33 +294,37 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
   float last_gain = st[SuppState::kLastGain];
   int memid = (int)st[SuppState::kMemId];
   for (int i = lane; i < kCepsMem * kRnnBands; i += 64) (&L.ceps[0][0])[i] = st[SuppState::kCeps + i];
+  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
+  const FftLane fl = fft_lane_init(tb.twiddle, lane);
+  float dctcol[kRnnBands];  // column `lane` of the DCT matrix (lanes < 22)
+#pragma unroll
+  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < kRnnBands ? lane : 0)];
   __syncthreads();
 
   for (int f = 0; f < a.n_frames; ++f) {
     const float *pb = xh + (int64_t)(f + 1) * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
-    for (int i = lane; i < kPitchBuf; i += 64) L.pbuf[i] = pb[i];
-    __syncthreads();
     // ---------------- frame_analysis: window, forward transform, band energy
     for (int i = lane; i < kRnnWindow; i += 64) {
       const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-      L.fa[i] = make_float2(L.pbuf[kPitchBuf - kRnnWindow + i] * w, 0.0f);
+      L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow + i] * w, 0.0f);
     }
     __syncthreads();
-    fft960_wave(L.fa, L.fb, tb.twiddle, lane, 1.0f / kRnnWindow);
+    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
     float2 *Xg = a.X + ((int64_t)f * a.n_streams + s) * kRnnFreq;
     for (int i = lane; i < kRnnFreq; i += 64) {
       L.X[i] = L.fb[i];
       Xg[i] = L.fb[i];
     }
     __syncthreads();
-    if (lane < kRnnBands) L.Ex[lane] = band_sum(L.X, L.X, lane);
+    if (lane < kRnnBands) L.Ex[lane] = band_sum(L.X, L.X, L.frac, lane);
     // ---------------- pitch_downsample (pitch.c): 2x decimation, LPC-4 whitening
     for (int i = lane; i < kPitchBuf / 2; i += 64)
-      L.ds[i] = i == 0 ? .5f * (.5f * L.pbuf[1] + L.pbuf[0])
-                       : .5f * (.5f * (L.pbuf[2 * i - 1] + L.pbuf[2 * i + 1]) + L.pbuf[2 * i]);
+      L.ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0])
+                       : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
     __syncthreads();
     if (lane < 5) {
       float d = 0.0f;
+#pragma unroll 8
       for (int i = lane; i < kPitchBuf / 2; ++i) d += L.ds[i] * L.ds[i - lane];
       L.misc[lane] = d;
     }
@@ -324,6 +392,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       // coarse: 4x decimated, 147 lags x 240 products (lane per lag, scalar summation order)
       for (int lag = lane; lag < (max_pitch >> 2); lag += 64) {
         float sum = 0.0f;
+#pragma unroll 8
         for (int j = 0; j < (kRnnWindow >> 2); ++j) sum += x_lp[2 * j] * L.ds[2 * (j + lag)];
         L.xc[lag] = sum;
       }
@@ -334,6 +403,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
         float Syy = 1.0f, bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
         int bp0 = 0, bp1 = 1;
         for (int j = 0; j < len; ++j) Syy += L.ds[2 * j] * L.ds[2 * j];
+#pragma unroll 4
         for (int i = 0; i < mp; ++i) {
           const float xv = L.xc[i];
           if (xv > 0) {
@@ -362,6 +432,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
         const int d0 = i - 2 * best0, d1 = i - 2 * best1;
         if (!((d0 > 2 || d0 < -2) && (d1 > 2 || d1 < -2))) {
           float sum = 0.0f;
+#pragma unroll 8
           for (int j = 0; j < (kRnnWindow >> 1); ++j) sum += x_lp[j] * L.ds[i + j];
           v = fmaxf(-1.0f, sum);
         }
@@ -373,6 +444,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
         float Syy = 1.0f, bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
         int bp0 = 0, bp1 = 1;
         for (int j = 0; j < len; ++j) Syy += L.ds[j] * L.ds[j];
+#pragma unroll 4
         for (int i = 0; i < mp; ++i) {
           const float xv = L.xc[i];
           if (xv > 0) {
@@ -445,6 +517,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       if (lane < n_cand) {
         const int lag = L.cand_lag[lane];
         float sum = 0.0f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) sum += x[j] * x[j - lag];
         L.cand[lane] = sum;
       }
@@ -455,6 +528,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       {
         float yy = xx;
         if (lane == 0) L.ylk[0] = xx;
+#pragma unroll 8
         for (int i = 1; i <= maxperiod; ++i) {
           yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
           if (lane == 0) L.ylk[i] = fmaxf(0.0f, yy);
@@ -492,6 +566,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       if (lane < 3) {
         const int lag = T + lane - 1;
         float sum = 0.0f;
+#pragma unroll 8
         for (int j = 0; j < N; ++j) sum += x[j] * x[j - lag];
         L.misc[8 + lane] = sum;
       }
@@ -510,15 +585,15 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
     // ---------------- pitch-aligned transform, band energy / correlation
     for (int i = lane; i < kRnnWindow; i += 64) {
       const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-      L.fa[i] = make_float2(L.pbuf[kPitchBuf - kRnnWindow - pitch_index + i] * w, 0.0f);
+      L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + i] * w, 0.0f);
     }
     __syncthreads();
-    fft960_wave(L.fa, L.fb, tb.twiddle, lane, 1.0f / kRnnWindow);
+    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
     float2 *Pg = a.P + ((int64_t)f * a.n_streams + s) * kRnnFreq;
     for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
     if (lane < kRnnBands) {
-      L.Ep[lane] = band_sum(L.fb, L.fb, lane);
-      L.Exp[lane] = band_sum(L.X, L.fb, lane);
+      L.Ep[lane] = band_sum(L.fb, L.fb, L.frac, lane);
+      L.Exp[lane] = band_sum(L.X, L.fb, L.frac, lane);
     }
     __syncthreads();
     if (lane < kRnnBands) L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
@@ -526,7 +601,8 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
     // ---------------- features (denoise.c compute_frame_features)
     if (lane < kRnnBands) {  // dct(tmp, Exp)
       float sum = 0;
-      for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * tb.dct[j * kRnnBands + lane];
+#pragma unroll
+      for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * dctcol[j];
       L.tmp22[lane] = sum * sqrtf(2.0f / 22);
     }
     __syncthreads();
@@ -551,7 +627,8 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       if (lane == 6) L.feat[kRnnBands + 18] = .01f * (pitch_index - 300);
       if (lane < kRnnBands) {  // dct(features, Ly)
         float sum = 0;
-        for (int j = 0; j < kRnnBands; ++j) sum += L.Ly[j] * tb.dct[j * kRnnBands + lane];
+#pragma unroll
+        for (int j = 0; j < kRnnBands; ++j) sum += L.Ly[j] * dctcol[j];
         float v = sum * sqrtf(2.0f / 22);
         if (lane == 0) v -= 12;
         if (lane == 1) v -= 4;
@@ -845,6 +922,8 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
 
 // ============================================================================== synthesis
 struct SynthLds {
+  float frac[404];
+  int32_t band_of[484];
   float2 fa[kRnnWindow], fb[kRnnWindow];
   float2 X[kRnnFreq + 3], P[kRnnFreq + 3];
   float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], g[kRnnBands], graw[kRnnBands], r[kRnnBands], norm[kRnnBands];
@@ -857,6 +936,9 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
   const int s = blockIdx.x;
   float *st = a.state + (int64_t)s * SuppState::kCount;
   for (int i = lane; i < kRnnFrame; i += 64) L.synth[i] = st[SuppState::kSynthMem + i];
+  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
+  for (int i = lane; i < 484; i += 64) L.band_of[i] = tb.band_of_bin[i];
+  const FftLane fl = fft_lane_init(tb.twiddle, lane);
   float smoothed = st[SuppState::kSmoothedStrength];
   __syncthreads();
   for (int f = 0; f < a.n_frames; ++f) {
@@ -889,19 +971,19 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
       }
       __syncthreads();
       for (int i = lane; i < kRnnFreq; i += 64) {
-        const float rf = interp_gain(L.r, i);
+        const float rf = interp_gain(L.r, L.frac, L.band_of, i);
         L.X[i].x += rf * L.P[i].x;
         L.X[i].y += rf * L.P[i].y;
       }
       __syncthreads();
-      if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + band_sum(L.X, L.X, lane)));
+      if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + band_sum(L.X, L.X, L.frac, lane)));
       __syncthreads();
       for (int i = lane; i < kRnnFreq; i += 64) {
-        const float nf = interp_gain(L.norm, i);
+        const float nf = interp_gain(L.norm, L.frac, L.band_of, i);
         float2 v = L.X[i];
         v.x *= nf;
         v.y *= nf;
-        const float gf = interp_gain(L.g, i);  // band gains after the lastg floor
+        const float gf = interp_gain(L.g, L.frac, L.band_of, i);  // band gains after the lastg floor
         v.x *= gf;
         v.y *= gf;
         L.X[i] = v;
@@ -912,7 +994,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
     for (int i = lane; i < kRnnWindow; i += 64)
       L.fa[i] = i < kRnnFreq ? L.X[i] : make_float2(L.X[kRnnWindow - i].x, -L.X[kRnnWindow - i].y);
     __syncthreads();
-    fft960_wave(L.fa, L.fb, tb.twiddle, lane, 1.0f);
+    fft960_wave(L.fa, L.fb, fl, lane, 1.0f);
     // wet/dry smoothing, rnnoise.rs:81-86 (once per frame)
     smoothed = a.strength * a.smoothing_coeff + smoothed * (1.0f - a.smoothing_coeff);
     const int64_t base = (int64_t)s * a.stream_stride + (a.frame0 + f) * kRnnFrame;
@@ -924,7 +1006,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
       float wet = (lo + L.synth[i]) / 32768.0f;
       carry[cnt] = hi;
       if (!a.raw_protocol && smoothed < 1.0f) {
-        const float dry = a.in[base + i];
+        const float dry = (a.front_clamp || a.front_dc) ? a.out[base + i] : a.in[base + i];
         wet = (smoothed * wet) + ((1.0f - smoothed) * dry);
       }
       a.out[base + i] = wet;

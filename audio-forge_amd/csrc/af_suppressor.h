@@ -68,6 +68,8 @@ struct SuppTables {
   const float *half_window;   // [480]
   const float *dct;           // [22*22]
   const float2 *twiddle;      // [960] exp(-2 pi i k / 960)
+  const float *frac;          // [404] position of a bin inside its band: (float)j / (float)band_size
+  const int32_t *band_of_bin; // [484] band index of a bin (bins >= 400 belong to no band: 21)
 };
 
 struct SuppArgs {
@@ -84,6 +86,12 @@ struct SuppArgs {
   float strength;             // wet/dry target (rnnoise.rs:70-79)
   float smoothing_coeff;      // rnnoise.rs:45-51
   int32_t raw_protocol;       // 1: rnnoise_benchmark.rs scaling (clamp*32768, no mix)
+  // optional realtime front end folded into the prefilter pass (routing.rs:802-843)
+  int32_t front_clamp, front_dc, front_hp;
+  double hp_b0, hp_b1, hp_b2, hp_a1, hp_a2;
+  double *chain_st64;         // chain state planes (pre-filter memories live there)
+  float *chain_st32;
+  int32_t f64_pre_z1, f32_dc_x1;  // field indices inside those planes
 };
 
 }  // namespace af

@@ -137,6 +137,21 @@ struct SuppressorHost {
       blob.push_back((float)std::cos(-2.0 * pi * i / kRnnWindow));
       blob.push_back((float)std::sin(-2.0 * pi * i / kRnnWindow));
     }
+    while (blob.size() % 4) blob.push_back(0.0f);
+    const size_t frac_off = blob.size();
+    const int eband[kRnnBands] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100};
+    std::vector<int32_t> band_of(484, kRnnBands - 1);
+    blob.resize(blob.size() + 404, 0.0f);
+    for (int b = 0; b < kRnnBands - 1; ++b) {
+      const int size = (eband[b + 1] - eband[b]) << 2;
+      for (int j = 0; j < size; ++j) {
+        blob[frac_off + (eband[b] << 2) + j] = (float)j / (float)size;
+        band_of[(eband[b] << 2) + j] = b;
+      }
+    }
+    const size_t band_off = blob.size();
+    blob.resize(blob.size() + 484);
+    std::memcpy(&blob[band_off], band_of.data(), 484 * sizeof(int32_t));
     if (blob.size() > blob_floats) {
       if (d_blob) (void)hipFree(d_blob);
       hipError_t err = hipMalloc(&d_blob, blob.size() * sizeof(float));
@@ -161,6 +176,8 @@ struct SuppressorHost {
     tables.half_window = d_blob + win_off;
     tables.dct = d_blob + dct_off;
     tables.twiddle = reinterpret_cast<const float2 *>(d_blob + tw_off);
+    tables.frac = d_blob + frac_off;
+    tables.band_of_bin = reinterpret_cast<const int32_t *>(d_blob + band_off);
     weights_dirty = false;
     return hipSuccess;
   }

@@ -84,6 +84,31 @@ def test_suppressor_then_chain(mi, oracle):
     assert float(np.sqrt(np.mean(d * d))) <= 2e-5
 
 
+def test_front_end_then_suppressor(mi, oracle):
+    """Realtime order (dsp_loop.rs:1222-1250,1521-1599): clamp -> DC block + 80 Hz HP -> suppressor, strength < 1 so the
+    dry path (the front end's output) is audible in the mix."""
+    x = (S.kat_signal(100, *S.stream_params(9)) * np.float32(1.7) + np.float32(0.05)).astype(np.float32)
+    import ctypes as C
+
+    L = oracle.lib()
+    L.afo_sanitize_and_clamp.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+    y = x.copy()
+    L.afo_sanitize_and_clamp(y.ctypes.data_as(C.POINTER(C.c_float)), y.size)
+    y = oracle.prefilter(y)
+    want = oracle.suppressor_process(y, 0.6, 0x5EED)
+    eng = mi.Engine(48_000.0, 1)
+    eng.set_eq_enabled(0)
+    eng.set_limiter_enabled(0)
+    eng.set_input_clamp_enabled(1)
+    eng.set_prefilter_enabled(1, 1)
+    eng.set_suppressor_enabled(1)
+    eng.set_suppressor_strength(0.6)
+    eng.set_control_block_samples(480)
+    got = eng.process(x.reshape(1, -1))[0]
+    eng.close()
+    _check(got, want)
+
+
 def test_frame_multiple_is_required(mi):
     eng = mi.Engine(48_000.0, 1)
     eng.set_suppressor_enabled(1)
