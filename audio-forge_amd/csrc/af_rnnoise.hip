@@ -8,13 +8,15 @@
 // (oracle/af_rnnoise.c) on seeded synthetic weights in the real layer layout.  Parity against the
 // crate itself is UNPINNED.
 //
-// Four kernels per window of frames:
+// Six kernels per window of frames:
 //   supp_prefilter_kernel  lane per stream: model-input scaling + RNNoise's 2nd-order high-pass over
 //                          samples (a recurrence), 64x64 tiles transposed through LDS.
-//   supp_analysis_kernel   wave per stream, frames in order: 960-point STFT, 22-band energies, the
-//                          pitch search (LPC-whitened 2x-decimated buffer, coarse + fine
-//                          cross-correlation, octave-error removal that depends on the previous
-//                          frame), pitch-aligned STFT, band correlation, 42 features.
+//   supp_spectrum_kernel   wave per (frame, stream): 960-point windowed transform, 22 band energies.
+//   supp_pitch_kernel      wave per stream, frames in order: LPC-whitened 2x-decimated buffer, coarse +
+//                          fine cross-correlation, octave-error removal (looks at the previous frame),
+//                          cepstral history and the features that come from it.
+//   supp_pitchspec_kernel  wave per (frame, stream): pitch-aligned transform, band correlation, its
+//                          cepstral features.
 //   supp_rnn_kernel        16 streams per workgroup, frames in order: dense(42->24), GRU24, GRU48,
 //                          GRU96, dense(96->22) on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
 //                          north_star asks for bf16 MFMA; bf16 activations (8 significant bits)
@@ -230,31 +232,55 @@ __device__ __forceinline__ void fft960_wave(float2 *a, float2 *b, const FftLane 
   __syncthreads();
 }
 
-// compute_band_energy / compute_band_corr: lane b accumulates band b in the order the scalar code does
-// (first the rising half fed by band b-1's bins, then the falling half of its own bins).  `frac` holds
-// (float)j / (float)band_size per bin, evaluated once on the host (the same IEEE division).
-__device__ __forceinline__ float band_sum(const float2 *X, const float2 *Pm, const float *frac, int b) {
+// ---- evaluation orders shared with the CPU restatement (oracle/af_rnnoise.c, "pitch tools") ----------
+// dot64: 64 interleaved partial sums (mul then add), xor-butterfly combine; every lane returns the total.
+__device__ __forceinline__ float wave_dot64(const float *x, const float *y, int n, int lane) {
+  float acc = 0.0f;
+#pragma unroll 4
+  for (int i = lane; i < n; i += 64) acc = acc + x[i] * y[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+  return acc;
+}
+// same with a stride-2 view of y (the 4x-decimated buffer is every second sample of the 2x one)
+__device__ __forceinline__ float wave_dot64_sq_stride2(const float *y, int n, int lane) {
+  float acc = 0.0f;
+  for (int i = lane; i < n; i += 64) acc = acc + y[2 * i] * y[2 * i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+  return acc;
+}
+
+// compute_band_energy / compute_band_corr: band b = R_b + F_b, the rising ramp over band b-1's bins and the
+// falling ramp over band b's bins, each summed left to right on its own lane (lane 2b, lane 2b+1).
+// `frac` holds (float)j / (float)band_size per bin, evaluated once on the host (the same IEEE division).
+// Lanes 0..21 return band `lane`.
+__device__ __forceinline__ float band_accumulate_wave(const float2 *X, const float2 *Pm, const float *frac, int lane) {
+  const int b = lane >> 1;
+  const bool falling = lane & 1;
   float sum = 0.0f;
-  if (b > 0) {
-    const int e0 = c_eband[b - 1] << 2, size = (c_eband[b] - c_eband[b - 1]) << 2;
+  if (lane < 2 * kRnnBands) {
+    if (!falling && b > 0) {
+      const int e0 = c_eband[b - 1] << 2, size = (c_eband[b] - c_eband[b - 1]) << 2;
 #pragma unroll 4
-    for (int j = 0; j < size; ++j) {
-      const float2 x = X[e0 + j], p = Pm[e0 + j];
-      const float tmp = x.x * p.x + x.y * p.y;
-      sum += frac[e0 + j] * tmp;
+      for (int j = 0; j < size; ++j) {
+        const float2 x = X[e0 + j], p = Pm[e0 + j];
+        sum += frac[e0 + j] * (x.x * p.x + x.y * p.y);
+      }
+    }
+    if (falling && b < kRnnBands - 1) {
+      const int e0 = c_eband[b] << 2, size = (c_eband[b + 1] - c_eband[b]) << 2;
+#pragma unroll 4
+      for (int j = 0; j < size; ++j) {
+        const float2 x = X[e0 + j], p = Pm[e0 + j];
+        sum += (1 - frac[e0 + j]) * (x.x * p.x + x.y * p.y);
+      }
     }
   }
-  if (b < kRnnBands - 1) {
-    const int e0 = c_eband[b] << 2, size = (c_eband[b + 1] - c_eband[b]) << 2;
-#pragma unroll 4
-    for (int j = 0; j < size; ++j) {
-      const float2 x = X[e0 + j], p = Pm[e0 + j];
-      const float tmp = x.x * p.x + x.y * p.y;
-      sum += (1 - frac[e0 + j]) * tmp;
-    }
-  }
-  if (b == 0 || b == kRnnBands - 1) sum *= 2;
-  return sum;
+  const float other = __shfl_down(sum, 1);  // lane 2b: rise + fall
+  float band = sum + other;
+  if (b == 0 || b == kRnnBands - 1) band *= 2;
+  return __shfl(band, (lane < kRnnBands ? lane : 0) * 2);  // lanes 0..21 pick band `lane`
 }
 
 // interp_band_gain value at one bin
@@ -265,37 +291,82 @@ __device__ __forceinline__ float interp_gain(const float *bandE, const float *fr
   return (1 - f) * bandE[b] + f * bandE[b + 1];
 }
 
-// ============================================================================== analysis
-struct AnalysisLds {
-  float frac[404];
-  float ds[kPitchBuf / 2];
+// ============================================================================== analysis, part 1
+// One wave per (frame, stream): window, forward transform, band energies.  Fully parallel.
+struct SpectrumLds {
   float2 fa[kRnnWindow], fb[kRnnWindow];
-  float2 X[kRnnFreq + 3];
-  float xc[304];
-  float ylk[(kPitchMax >> 1) + 4];
-  float ceps[kCepsMem][kRnnBands];
-  float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], Ly[kRnnBands], tmp22[kRnnBands + 2];
-  float feat[kRnnFeatPad];
-  float dist[kCepsMem][kCepsMem];
-  float cand[64];
-  int cand_lag[64];
-  float misc[16];
+  float frac[404];
 };
 
-extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a, SuppTables tb) {
-  __shared__ AnalysisLds L;
+extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ SpectrumLds L;
+  const int lane = threadIdx.x;
+  const int64_t cell = blockIdx.x;
+  const int f = (int)(cell / a.n_streams), s = (int)(cell % a.n_streams);
+  const int64_t n = (int64_t)a.n_frames * kRnnFrame;
+  const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
+  const FftLane fl = fft_lane_init(tb.twiddle, lane);
+  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
+  for (int i = lane; i < kRnnWindow; i += 64) {
+    const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+    L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow + i] * w, 0.0f);
+  }
+  __syncthreads();
+  fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+  float2 *Xg = a.X + cell * kRnnFreq;
+  for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fb[i];
+  const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
+  if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
+}
+
+// ============================================================================== analysis, part 2
+// One wave per stream, frames in order: pitch (the octave-error removal looks at the previous frame) and the
+// cepstral history.  Everything it touches is small, so sixteen of these waves share a CU.
+struct PitchLds {
+  float ds[kPitchBuf / 2];
+  float xc[304];
+  float numa[304], da[304];
+  float ylk[(kPitchMax >> 1) + 4];
+  float ceps[kCepsMem][kRnnBands];
+  float Ex[kRnnBands], Ly[kRnnBands];
+  float feat[kRnnFeatPad];
+  float dist[kCepsMem][kCepsMem];
+};
+
+// find_best_pitch (pitch.c) over precomputed numerators / energy deltas; every lane walks the same recurrence
+__device__ __forceinline__ void best_pitch_scan(const float *numa, const float *da, float Syy, int mp, int &bp0, int &bp1) {
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  bp0 = 0;
+  bp1 = 1;
+#pragma unroll 4
+  for (int i = 0; i < mp; ++i) {
+    const float num = numa[i];
+    if (num >= 0.0f) {
+      if (num * bd1 > bn1 * Syy) {
+        if (num * bd0 > bn0 * Syy) {
+          bn1 = bn0; bd1 = bd0; bp1 = bp0;
+          bn0 = num; bd0 = Syy; bp0 = i;
+        } else {
+          bn1 = num; bd1 = Syy; bp1 = i;
+        }
+      }
+    }
+    Syy += da[i];
+    Syy = fmaxf(1.0f, Syy);
+  }
+}
+
+extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ PitchLds L;
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
   const float *xh = a.xh + (int64_t)s * (kPitchBuf + n);
   float *st = a.state + (int64_t)s * SuppState::kCount;
-
   int last_period = (int)st[SuppState::kLastPeriod];
   float last_gain = st[SuppState::kLastGain];
   int memid = (int)st[SuppState::kMemId];
   for (int i = lane; i < kCepsMem * kRnnBands; i += 64) (&L.ceps[0][0])[i] = st[SuppState::kCeps + i];
-  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  const FftLane fl = fft_lane_init(tb.twiddle, lane);
   float dctcol[kRnnBands];  // column `lane` of the DCT matrix (lanes < 22)
 #pragma unroll
   for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < kRnnBands ? lane : 0)];
@@ -303,36 +374,17 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
 
   for (int f = 0; f < a.n_frames; ++f) {
     const float *pb = xh + (int64_t)(f + 1) * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
-    // ---------------- frame_analysis: window, forward transform, band energy
-    for (int i = lane; i < kRnnWindow; i += 64) {
-      const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-      L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow + i] * w, 0.0f);
-    }
-    __syncthreads();
-    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
-    float2 *Xg = a.X + ((int64_t)f * a.n_streams + s) * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) {
-      L.X[i] = L.fb[i];
-      Xg[i] = L.fb[i];
-    }
-    __syncthreads();
-    if (lane < kRnnBands) L.Ex[lane] = band_sum(L.X, L.X, L.frac, lane);
+    SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
+    if (lane < kRnnBands) L.Ex[lane] = rec->Ex[lane];
     // ---------------- pitch_downsample (pitch.c): 2x decimation, LPC-4 whitening
     for (int i = lane; i < kPitchBuf / 2; i += 64)
-      L.ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0])
-                       : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
-    __syncthreads();
-    if (lane < 5) {
-      float d = 0.0f;
-#pragma unroll 8
-      for (int i = lane; i < kPitchBuf / 2; ++i) d += L.ds[i] * L.ds[i - lane];
-      L.misc[lane] = d;
-    }
+      L.ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0]) : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
     __syncthreads();
     float n0, n1, n2, n3, n4;
     {
       float ac[5];
-      for (int i = 0; i < 5; ++i) ac[i] = L.misc[i];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ac[k] = wave_dot64(L.ds + k, L.ds, kPitchBuf / 2 - k, lane);
       ac[0] *= 1.0001f;
       for (int i = 1; i <= 4; ++i) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
       float lpc[4] = {0, 0, 0, 0};
@@ -365,7 +417,6 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       n3 = lpc[3] + c1 * lpc[2];
       n4 = c1 * lpc[3];
     }
-    __syncthreads();
     {
       // celt_fir5 with zero initial memory: y[i] = x[i] + n0 x[i-1] + ... + n4 x[i-5], in that order
       float yv[14];
@@ -386,86 +437,54 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
     __syncthreads();
     // ---------------- pitch_search(x_lp = ds + 384, y = ds, len 960, max_pitch 588)
     const int max_pitch = kPitchMax - 3 * kPitchMin;  // 588
+    const float *x_lp = L.ds + (kPitchMax >> 1);
     int best0, best1;
     {
-      const float *x_lp = L.ds + (kPitchMax >> 1);
-      // coarse: 4x decimated, 147 lags x 240 products (lane per lag, scalar summation order)
-      for (int lag = lane; lag < (max_pitch >> 2); lag += 64) {
+      // coarse: 4x decimated, 147 lags x 240 products (lane per lag, left-to-right order)
+      const int len = kRnnWindow >> 2, mp = max_pitch >> 2;
+      for (int lag = lane; lag < mp; lag += 64) {
         float sum = 0.0f;
 #pragma unroll 8
-        for (int j = 0; j < (kRnnWindow >> 2); ++j) sum += x_lp[2 * j] * L.ds[2 * (j + lag)];
-        L.xc[lag] = sum;
+        for (int j = 0; j < len; ++j) sum += x_lp[2 * j] * L.ds[2 * (j + lag)];
+        const float x16 = sum * 1e-12f;
+        L.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
+        const float ya = L.ds[2 * (lag + len)], yb = L.ds[2 * lag];
+        L.da[lag] = ya * ya - yb * yb;
+      }
+      const float Syy0 = 1.0f + wave_dot64_sq_stride2(L.ds, len, lane);
+      __syncthreads();
+      best_pitch_scan(L.numa, L.da, Syy0, mp, best0, best1);
+    }
+    __syncthreads();
+    {
+      // fine: 2x decimated, only within +-2 of the two coarse candidates (at most ten lags)
+      const int len = kRnnWindow >> 1, mp = max_pitch >> 1;
+      for (int i = lane; i < mp; i += 64) {
+        L.xc[i] = 0.0f;
+        L.numa[i] = -1.0f;
+        const float ya = L.ds[i + len], yb = L.ds[i];
+        L.da[i] = ya * ya - yb * yb;
       }
       __syncthreads();
-      // find_best_pitch (uniform: every lane walks the same recurrence)
-      {
-        const int len = kRnnWindow >> 2, mp = max_pitch >> 2;
-        float Syy = 1.0f, bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-        int bp0 = 0, bp1 = 1;
-        for (int j = 0; j < len; ++j) Syy += L.ds[2 * j] * L.ds[2 * j];
-#pragma unroll 4
-        for (int i = 0; i < mp; ++i) {
-          const float xv = L.xc[i];
-          if (xv > 0) {
-            const float x16 = xv * 1e-12f;
-            const float num = x16 * x16;
-            if (num * bd1 > bn1 * Syy) {
-              if (num * bd0 > bn0 * Syy) {
-                bn1 = bn0; bd1 = bd0; bp1 = bp0;
-                bn0 = num; bd0 = Syy; bp0 = i;
-              } else {
-                bn1 = num; bd1 = Syy; bp1 = i;
-              }
-            }
+      for (int c = 0; c < 2; ++c) {
+        const int centre = 2 * (c == 0 ? best0 : best1);
+        for (int i = centre - 2; i <= centre + 2; ++i) {
+          if (i < 0 || i >= mp) continue;
+          if (c == 1) {
+            const int d0 = i - 2 * best0;
+            if (d0 <= 2 && d0 >= -2) continue;  // already done for the first candidate
           }
-          const float ya = L.ds[2 * (i + len)], yb = L.ds[2 * i];
-          Syy += ya * ya - yb * yb;
-          Syy = fmaxf(1.0f, Syy);
-        }
-        best0 = bp0;
-        best1 = bp1;
-      }
-      __syncthreads();
-      // fine: 2x decimated, only near the two coarse candidates
-      for (int i = lane; i < (max_pitch >> 1); i += 64) {
-        float v = 0.0f;
-        const int d0 = i - 2 * best0, d1 = i - 2 * best1;
-        if (!((d0 > 2 || d0 < -2) && (d1 > 2 || d1 < -2))) {
-          float sum = 0.0f;
-#pragma unroll 8
-          for (int j = 0; j < (kRnnWindow >> 1); ++j) sum += x_lp[j] * L.ds[i + j];
-          v = fmaxf(-1.0f, sum);
-        }
-        L.xc[i] = v;
-      }
-      __syncthreads();
-      {
-        const int len = kRnnWindow >> 1, mp = max_pitch >> 1;
-        float Syy = 1.0f, bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
-        int bp0 = 0, bp1 = 1;
-        for (int j = 0; j < len; ++j) Syy += L.ds[j] * L.ds[j];
-#pragma unroll 4
-        for (int i = 0; i < mp; ++i) {
-          const float xv = L.xc[i];
-          if (xv > 0) {
-            const float x16 = xv * 1e-12f;
-            const float num = x16 * x16;
-            if (num * bd1 > bn1 * Syy) {
-              if (num * bd0 > bn0 * Syy) {
-                bn1 = bn0; bd1 = bd0; bp1 = bp0;
-                bn0 = num; bd0 = Syy; bp0 = i;
-              } else {
-                bn1 = num; bd1 = Syy; bp1 = i;
-              }
-            }
+          const float v = fmaxf(-1.0f, wave_dot64(x_lp, L.ds + i, len, lane));
+          if (lane == 0) {
+            L.xc[i] = v;
+            const float x16 = v * 1e-12f;
+            L.numa[i] = v > 0 ? x16 * x16 : -1.0f;
           }
-          const float ya = L.ds[i + len], yb = L.ds[i];
-          Syy += ya * ya - yb * yb;
-          Syy = fmaxf(1.0f, Syy);
         }
-        best0 = bp0;
-        best1 = bp1;
       }
+      const float Syy0 = 1.0f + wave_dot64(L.ds, L.ds, len, lane);
+      __syncthreads();
+      best_pitch_scan(L.numa, L.da, Syy0, mp, best0, best1);
     }
     int pitch_index;
     {
@@ -487,51 +506,31 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       const int prev_period = last_period / 2;
       const float *x = L.ds + maxperiod;
       if (T0 >= maxperiod) T0 = maxperiod - 1;
-      // candidate lags: [0]=0 (xx), [1]=T0, then (T1, T1b) for k = 2..15
-      int n_cand = 2;
-      int T1s[16], T1bs[16];
-      int kmax = 1;
-      for (int k = 2; k <= 15; ++k) {
-        const int T1 = (2 * T0 + k) / (2 * k);
-        if (T1 < minperiod) break;
-        int T1b;
-        if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
-        else {
-          const int sc2[16] = {0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2};
-          T1b = (2 * sc2[k] * T0 + k) / (2 * k);
-        }
-        T1s[k] = T1;
-        T1bs[k] = T1b;
-        kmax = k;
-        n_cand += 2;
-      }
-      if (lane == 0) {
-        L.cand_lag[0] = 0;
-        L.cand_lag[1] = T0;
-        for (int k = 2; k <= kmax; ++k) {
-          L.cand_lag[2 * k - 2] = T1s[k];
-          L.cand_lag[2 * k - 1] = T1bs[k];
-        }
-      }
-      __syncthreads();
-      if (lane < n_cand) {
-        const int lag = L.cand_lag[lane];
-        float sum = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < N; ++j) sum += x[j] * x[j - lag];
-        L.cand[lane] = sum;
-      }
-      __syncthreads();
-      const float xx = L.cand[0];
-      float xy = L.cand[1];
-      // yy_lookup recurrence (uniform)
+      const float xx = wave_dot64(x, x, N, lane);
+      float xy = wave_dot64(x, x - T0, N, lane);
       {
-        float yy = xx;
+        // yy_lookup[i] = max(0, xx + prefix_i), prefix over e_i = x[-i]^2 - x[N-i]^2 in the blocked scan order
+        const int chunk = (maxperiod + 63) / 64;  // 6
+        float local[6];
+        float acc = 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          const int i = lane * chunk + k2 + 1;  // 1-based lag
+          if (i <= maxperiod) acc = acc + (x[-i] * x[-i] - x[N - i] * x[N - i]);
+          local[k2] = acc;
+        }
+        float total = acc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float other = __shfl_up(total, off);
+          if (lane >= off) total = total + other;
+        }
+        const float before = __shfl_up(total, 1);
         if (lane == 0) L.ylk[0] = xx;
-#pragma unroll 8
-        for (int i = 1; i <= maxperiod; ++i) {
-          yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
-          if (lane == 0) L.ylk[i] = fmaxf(0.0f, yy);
+#pragma unroll
+        for (int k2 = 0; k2 < 6; ++k2) {
+          const int i = lane * chunk + k2 + 1;
+          if (i <= maxperiod) L.ylk[i] = fmaxf(0.0f, xx + (lane == 0 ? local[k2] : before + local[k2]));
         }
       }
       __syncthreads();
@@ -540,15 +539,22 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       const float g0 = xy / sqrtf(1 + xx * yy);
       float g = g0;
       int T = T0;
-      for (int k = 2; k <= kmax; ++k) {
-        const int T1 = T1s[k], T1b = T1bs[k];
-        xy = .5f * (L.cand[2 * k - 2] + L.cand[2 * k - 1]);
+      for (int k2 = 2; k2 <= 15; ++k2) {
+        const int T1 = (2 * T0 + k2) / (2 * k2);
+        if (T1 < minperiod) break;
+        int T1b;
+        if (k2 == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+        else {
+          const int sc2 = (k2 == 6 || k2 == 12) ? 5 : ((k2 & 1) ? 2 : 3);  // second_check[k]
+          T1b = (2 * sc2 * T0 + k2) / (2 * k2);
+        }
+        xy = .5f * (wave_dot64(x, x - T1, N, lane) + wave_dot64(x, x - T1b, N, lane));
         yy = .5f * (L.ylk[T1] + L.ylk[T1b]);
         const float g1 = xy / sqrtf(1 + xx * yy);
         float cont;
         const int dT = T1 - prev_period;
         if (dT <= 1 && dT >= -1) cont = last_gain;
-        else if (dT <= 2 && dT >= -2 && 5 * k * k < T0) cont = .5f * last_gain;
+        else if (dT <= 2 && dT >= -2 && 5 * k2 * k2 < T0) cont = .5f * last_gain;
         else cont = 0;
         float thresh = fmaxf(.3f, .7f * g0 - cont);
         if (T1 < 3 * minperiod) thresh = fmaxf(.4f, .85f * g0 - cont);
@@ -562,17 +568,10 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       }
       best_xy = fmaxf(0.0f, best_xy);
       float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1);
-      __syncthreads();
-      if (lane < 3) {
-        const int lag = T + lane - 1;
-        float sum = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < N; ++j) sum += x[j] * x[j - lag];
-        L.misc[8 + lane] = sum;
-      }
-      __syncthreads();
+      const float c0 = wave_dot64(x, x - (T - 1), N, lane);
+      const float c1v = wave_dot64(x, x - T, N, lane);
+      const float c2 = wave_dot64(x, x - (T + 1), N, lane);
       int offset = 0;
-      const float c0 = L.misc[8], c1v = L.misc[9], c2 = L.misc[10];
       if ((c2 - c0) > .7f * (c1v - c0)) offset = 1;
       else if ((c0 - c2) > .7f * (c1v - c2)) offset = -1;
       if (pg > g) pg = g;
@@ -582,30 +581,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
     }
     last_period = pitch_index;
     last_gain = gain;
-    // ---------------- pitch-aligned transform, band energy / correlation
-    for (int i = lane; i < kRnnWindow; i += 64) {
-      const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-      L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + i] * w, 0.0f);
-    }
-    __syncthreads();
-    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
-    float2 *Pg = a.P + ((int64_t)f * a.n_streams + s) * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
-    if (lane < kRnnBands) {
-      L.Ep[lane] = band_sum(L.fb, L.fb, L.frac, lane);
-      L.Exp[lane] = band_sum(L.X, L.fb, L.frac, lane);
-    }
-    __syncthreads();
-    if (lane < kRnnBands) L.Exp[lane] = L.Exp[lane] / sqrtf(.001f + L.Ex[lane] * L.Ep[lane]);
-    __syncthreads();
-    // ---------------- features (denoise.c compute_frame_features)
-    if (lane < kRnnBands) {  // dct(tmp, Exp)
-      float sum = 0;
-#pragma unroll
-      for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * dctcol[j];
-      L.tmp22[lane] = sum * sqrtf(2.0f / 22);
-    }
-    __syncthreads();
+    // ---------------- features that do not need the pitch spectrum (denoise.c compute_frame_features)
     float E = 0.0f;
     {
       float logMax = -2, follow = -2;
@@ -619,11 +595,9 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       }
     }
     const bool silence = E < 0.04f;
-    __syncthreads();
     if (lane < kRnnFeatPad) L.feat[lane] = 0.0f;
     __syncthreads();
     if (!silence) {
-      if (lane < 6) L.feat[kRnnBands + 12 + lane] = L.tmp22[lane] - (lane == 0 ? 1.3f : (lane == 1 ? 0.9f : 0.0f));
       if (lane == 6) L.feat[kRnnBands + 18] = .01f * (pitch_index - 300);
       if (lane < kRnnBands) {  // dct(features, Ly)
         float sum = 0;
@@ -648,8 +622,8 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       {  // spectral variability: lane (i, j) owns one pair
         const int i = lane >> 3, j = lane & 7;
         float dist = 0;
-        for (int k = 0; k < kRnnBands; ++k) {
-          const float t = L.ceps[i][k] - L.ceps[j][k];
+        for (int k2 = 0; k2 < kRnnBands; ++k2) {
+          const float t = L.ceps[i][k2] - L.ceps[j][k2];
           dist += t * t;
         }
         L.dist[i][j] = dist;
@@ -667,12 +641,6 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
       }
     }
     __syncthreads();
-    SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
-    if (lane < kRnnBands) {
-      rec->Ex[lane] = L.Ex[lane];
-      rec->Ep[lane] = L.Ep[lane];
-      rec->Exp[lane] = L.Exp[lane];
-    }
     if (lane < kRnnFeatPad) rec->feat[lane] = L.feat[lane];
     if (lane == 0) {
       rec->silence = silence ? 1 : 0;
@@ -688,6 +656,57 @@ extern "C" __global__ __launch_bounds__(64) void supp_analysis_kernel(SuppArgs a
   for (int i = lane; i < kCepsMem * kRnnBands; i += 64) st[SuppState::kCeps + i] = (&L.ceps[0][0])[i];
   // the last 1728 model-input samples become the next window's history
   for (int i = lane; i < kPitchBuf; i += 64) st[SuppState::kHist + i] = xh[n + i];
+}
+
+// ============================================================================== analysis, part 3
+// One wave per (frame, stream): pitch-aligned transform, band energy / correlation, their cepstral features.
+struct PitchSpecLds {
+  float2 fa[kRnnWindow], fb[kRnnWindow];
+  float2 X[kRnnFreq + 3];
+  float frac[404];
+  float Exp[kRnnBands];
+};
+
+extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ PitchSpecLds L;
+  const int lane = threadIdx.x;
+  const int64_t cell = blockIdx.x;
+  const int f = (int)(cell / a.n_streams), s = (int)(cell % a.n_streams);
+  const int64_t n = (int64_t)a.n_frames * kRnnFrame;
+  const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
+  SuppFrameRec *rec = a.rec + cell;
+  const int pitch_index = rec->pitch_index;
+  const bool silence = rec->silence != 0;
+  const FftLane fl = fft_lane_init(tb.twiddle, lane);
+  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
+  const float2 *Xg = a.X + cell * kRnnFreq;
+  for (int i = lane; i < kRnnFreq; i += 64) L.X[i] = Xg[i];
+  for (int i = lane; i < kRnnWindow; i += 64) {
+    const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+    L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + i] * w, 0.0f);
+  }
+  __syncthreads();
+  fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+  float2 *Pg = a.P + cell * kRnnFreq;
+  for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
+  const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
+  float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane);
+  if (lane < kRnnBands) {
+    const float ex = rec->Ex[lane];
+    exp_ = exp_ / sqrtf(.001f + ex * ep);
+    rec->Ep[lane] = ep;
+    rec->Exp[lane] = exp_;
+    L.Exp[lane] = exp_;
+  }
+  __syncthreads();
+  if (!silence && lane < 6) {  // dct(tmp, Exp), first six coefficients
+    float sum = 0;
+    for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * tb.dct[j * kRnnBands + lane];
+    float v = sum * sqrtf(2.0f / 22);
+    if (lane == 0) v -= 1.3f;
+    if (lane == 1) v -= 0.9f;
+    rec->feat[kRnnBands + 12 + lane] = v;
+  }
 }
 
 // ============================================================================== network
@@ -930,7 +949,7 @@ struct SynthLds {
   float synth[kRnnFrame];
 };
 
-extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs a, SuppTables tb) {
+extern "C" __global__ __launch_bounds__(64, 2) void supp_synthesis_kernel(SuppArgs a, SuppTables tb) {
   __shared__ SynthLds L;
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
@@ -976,7 +995,10 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
         L.X[i].y += rf * L.P[i].y;
       }
       __syncthreads();
-      if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + band_sum(L.X, L.X, L.frac, lane)));
+      {
+        const float newE = band_accumulate_wave(L.X, L.X, L.frac, lane);
+        if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + newE));
+      }
       __syncthreads();
       for (int i = lane; i < kRnnFreq; i += 64) {
         const float nf = interp_gain(L.norm, L.frac, L.band_of, i);
@@ -1023,7 +1045,9 @@ extern "C" __global__ __launch_bounds__(64) void supp_synthesis_kernel(SuppArgs 
 // ============================================================================== launch
 hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
   hipLaunchKernelGGL(supp_prefilter_kernel, dim3((a.n_streams + 63) / 64), dim3(64), 0, stream, a);
-  hipLaunchKernelGGL(supp_analysis_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_spectrum_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
   hipLaunchKernelGGL(supp_synthesis_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
   return hipGetLastError();

@@ -89,6 +89,7 @@ struct SuppArgs {
   // optional realtime front end folded into the prefilter pass (routing.rs:802-843)
   int32_t front_clamp, front_dc, front_hp;
   double hp_b0, hp_b1, hp_b2, hp_a1, hp_a2;
+  long long *dbg;             // optional: per-section shader-clock totals of workgroup 0 (development aid)
   double *chain_st64;         // chain state planes (pre-filter memories live there)
   float *chain_st32;
   int32_t f64_pre_z1, f32_dc_x1;  // field indices inside those planes

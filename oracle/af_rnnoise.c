@@ -120,39 +120,27 @@ static void apply_window(float *x) {
 }
 
 /* ------------------------------------------------------------ band tools */
-static void compute_band_energy(float *bandE, const cpx *X) {
-  float sum[NB] = {0};
-  for (int i = 0; i < NB - 1; ++i) {
-    int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
-    for (int j = 0; j < band_size; ++j) {
-      float frac = (float)j / band_size;
-      const cpx v = X[(eband5ms[i] << 2) + j];
-      float tmp = v.r * v.r + v.i * v.i;
-      sum[i] += (1 - frac) * tmp;
-      sum[i + 1] += frac * tmp;
-    }
-  }
-  sum[0] *= 2;
-  sum[NB - 1] *= 2;
-  memcpy(bandE, sum, sizeof sum);
-}
-
-static void compute_band_corr(float *bandE, const cpx *X, const cpx *P) {
-  float sum[NB] = {0};
+/* Band b = R_b + F_b: R_b sums the rising ramp over band b-1's bins, F_b the falling ramp over band b's bins
+ * (each left to right).  The scalar C interleaves both into one accumulator; two accumulators map to two
+ * lanes on the GPU and differ from that only in the last rounding. */
+static void band_accumulate(float *bandE, const cpx *X, const cpx *P) {
+  float rise[NB] = {0}, fall[NB] = {0};
   for (int i = 0; i < NB - 1; ++i) {
     int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
     for (int j = 0; j < band_size; ++j) {
       float frac = (float)j / band_size;
       int idx = (eband5ms[i] << 2) + j;
       float tmp = X[idx].r * P[idx].r + X[idx].i * P[idx].i;
-      sum[i] += (1 - frac) * tmp;
-      sum[i + 1] += frac * tmp;
+      fall[i] += (1 - frac) * tmp;
+      rise[i + 1] += frac * tmp;
     }
   }
-  sum[0] *= 2;
-  sum[NB - 1] *= 2;
-  memcpy(bandE, sum, sizeof sum);
+  for (int i = 0; i < NB; ++i) bandE[i] = rise[i] + fall[i];
+  bandE[0] *= 2;
+  bandE[NB - 1] *= 2;
 }
+static void compute_band_energy(float *bandE, const cpx *X) { band_accumulate(bandE, X, X); }
+static void compute_band_corr(float *bandE, const cpx *X, const cpx *P) { band_accumulate(bandE, X, P); }
 
 static void interp_band_gain(float *g /*FREQ*/, const float *bandE) {
   memset(g, 0, sizeof(float) * FREQ);
@@ -173,11 +161,62 @@ static void dct(float *out, const float *in) {
   }
 }
 
-/* ------------------------------------------------------------ pitch tools */
+/* ------------------------------------------------------------ pitch tools
+ * Evaluation order.  The scalar C of RNNoise sums long dot products left to right; the Rust crate the
+ * reference uses unrolls them over several accumulators, so no single order is "the" reference order.
+ * This restatement fixes one that a 64-lane wavefront evaluates natively, and the GPU kernels use the
+ * very same one:
+ *   dot64(x, y, n): 64 interleaved partial sums p[l] = sum_m x[l+64m]*y[l+64m] (mul then add, m ascending),
+ *                   combined by the xor butterfly p[l] += p[l^32], ^16, ^8, ^4, ^2, ^1.
+ *   scan64(e, n):   prefix sums with each lane owning ceil(n/64) consecutive terms: sequential prefix inside
+ *                   a lane, Hillis-Steele inclusive scan of the 64 lane totals, one add of the offset.
+ * The short lag-parallel correlations (coarse pitch search) keep the plain left-to-right order. */
 static float inner_prod(const float *x, const float *y, int n) {
   float s = 0;
   for (int i = 0; i < n; ++i) s += x[i] * y[i];
   return s;
+}
+
+static float dot64(const float *x, const float *y, int n) {
+  float p[64];
+  for (int l = 0; l < 64; ++l) {
+    float acc = 0.0f;
+    for (int i = l; i < n; i += 64) acc = acc + x[i] * y[i];
+    p[l] = acc;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    float q[64];
+    for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+    memcpy(p, q, sizeof p);
+  }
+  return p[0];
+}
+
+/* out[i] = e[0] + ... + e[i] for i < n (n <= 64 * 8) in the blocked order described above */
+static void scan64(const float *e, float *out, int n) {
+  const int chunk = (n + 63) / 64;
+  float total[64], local[512];
+  for (int l = 0; l < 64; ++l) {
+    float acc = 0.0f;
+    for (int k = 0; k < chunk; ++k) {
+      const int i = l * chunk + k;
+      if (i < n) {
+        acc = acc + e[i];
+        local[i] = acc;
+      }
+    }
+    total[l] = acc;
+  }
+  for (int off = 1; off < 64; off <<= 1) {
+    float q[64];
+    for (int l = 0; l < 64; ++l) q[l] = l >= off ? total[l] + total[l - off] : total[l];
+    memcpy(total, q, sizeof total);
+  }
+  for (int l = 0; l < 64; ++l)
+    for (int k = 0; k < chunk; ++k) {
+      const int i = l * chunk + k;
+      if (i < n) out[i] = l == 0 ? local[i] : total[l - 1] + local[i];
+    }
 }
 
 static void pitch_xcorr(const float *x, const float *y, float *xcorr, int len, int max_pitch) {
@@ -211,11 +250,7 @@ static void pitch_downsample(const float *x, float *x_lp, int len) {
   for (int i = 1; i < half; ++i) x_lp[i] = .5f * (.5f * (x[2 * i - 1] + x[2 * i + 1]) + x[2 * i]);
   x_lp[0] = .5f * (.5f * x[1] + x[0]);
   float ac[5];
-  for (int k = 0; k <= 4; ++k) {
-    float d = 0;
-    for (int i = k; i < half; ++i) d += x_lp[i] * x_lp[i - k];
-    ac[k] = d;
-  }
+  for (int k = 0; k <= 4; ++k) ac[k] = dot64(x_lp + k, x_lp, half - k);
   ac[0] *= 1.0001f;
   for (int i = 1; i <= 4; ++i) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
   float lpc[4];
@@ -246,7 +281,7 @@ static void find_best_pitch(const float *xcorr, const float *y, int len, int max
   float best_num[2] = {-1, -1}, best_den[2] = {0, 0};
   best_pitch[0] = 0;
   best_pitch[1] = 1;
-  for (int j = 0; j < len; ++j) Syy += y[j] * y[j];
+  Syy = 1.0f + dot64(y, y, len);
   for (int i = 0; i < max_pitch; ++i) {
     if (xcorr[i] > 0) {
       float xcorr16 = xcorr[i] * 1e-12f;
@@ -276,7 +311,7 @@ static void pitch_search(const float *x_lp, const float *y, int len, int max_pit
   for (int i = 0; i < max_pitch >> 1; ++i) {
     xcorr[i] = 0;
     if (abs(i - 2 * best_pitch[0]) > 2 && abs(i - 2 * best_pitch[1]) > 2) continue;
-    float sum = inner_prod(x_lp, y + i, len >> 1);
+    float sum = dot64(x_lp, y + i, len >> 1);
     xcorr[i] = fmaxf(-1, sum);
   }
   find_best_pitch(xcorr, y, len >> 1, max_pitch >> 1, best_pitch);
@@ -302,14 +337,15 @@ static float remove_doubling(const float *x, int maxperiod, int minperiod, int N
   int T, T0;
   T = T0 = *T0_;
   float yy_lookup[(PMAX >> 1) + 1];
-  float xx = inner_prod(x, x, N), xy = inner_prod(x, x - T0, N);
+  float xx = dot64(x, x, N), xy = dot64(x, x - T0, N);
   yy_lookup[0] = xx;
-  float yy = xx;
-  for (int i = 1; i <= maxperiod; ++i) {
-    yy = yy + x[-i] * x[-i] - x[N - i] * x[N - i];
-    yy_lookup[i] = fmaxf(0, yy);
+  {
+    float e[PMAX >> 1], S[PMAX >> 1];
+    for (int i = 1; i <= maxperiod; ++i) e[i - 1] = x[-i] * x[-i] - x[N - i] * x[N - i];
+    scan64(e, S, maxperiod);
+    for (int i = 1; i <= maxperiod; ++i) yy_lookup[i] = fmaxf(0, xx + S[i - 1]);
   }
-  yy = yy_lookup[T0];
+  float yy = yy_lookup[T0];
   float best_xy = xy, best_yy = yy;
   float g, g0;
   g = g0 = compute_pitch_gain(xy, xx, yy);
@@ -319,7 +355,7 @@ static float remove_doubling(const float *x, int maxperiod, int minperiod, int N
     int T1b;
     if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
     else T1b = (2 * second_check[k] * T0 + k) / (2 * k);
-    float xy1 = inner_prod(x, x - T1, N), xy2 = inner_prod(x, x - T1b, N);
+    float xy1 = dot64(x, x - T1, N), xy2 = dot64(x, x - T1b, N);
     xy = .5f * (xy1 + xy2);
     yy = .5f * (yy_lookup[T1] + yy_lookup[T1b]);
     float g1 = compute_pitch_gain(xy, xx, yy);
@@ -335,7 +371,7 @@ static float remove_doubling(const float *x, int maxperiod, int minperiod, int N
   best_xy = fmaxf(0, best_xy);
   float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1);
   float xc[3];
-  for (int k = 0; k < 3; ++k) xc[k] = inner_prod(x, x - (T + k - 1), N);
+  for (int k = 0; k < 3; ++k) xc[k] = dot64(x, x - (T + k - 1), N);
   int offset = 0;
   if ((xc[2] - xc[0]) > .7f * (xc[1] - xc[0])) offset = 1;
   else if ((xc[0] - xc[2]) > .7f * (xc[1] - xc[2])) offset = -1;
