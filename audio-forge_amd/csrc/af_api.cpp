@@ -578,7 +578,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       sa.f64_pre_z1 = af::kPreZ1;
       sa.f32_dc_x1 = af::kDcX1;
       AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
-      e->last_launches += 6;
+      e->last_launches += 7;
     }
     chain_in = out;
   }

@@ -8,7 +8,7 @@
 // (oracle/af_rnnoise.c) on seeded synthetic weights in the real layer layout.  Parity against the
 // crate itself is UNPINNED.
 //
-// Six kernels per window of frames:
+// Seven kernels per window of frames:
 //   supp_prefilter_kernel  lane per stream: model-input scaling + RNNoise's 2nd-order high-pass over
 //                          samples (a recurrence), 64x64 tiles transposed through LDS.
 //   supp_spectrum_kernel   wave per (frame, stream): 960-point windowed transform, 22 band energies.
@@ -24,8 +24,9 @@
 //                          budget.  The f32-input MFMA is an exact k-ordered fmaf chain, which lets
 //                          this stage match the CPU restatement, and at ~0.2 GFLOP per stream-second
 //                          the network is three orders of magnitude below even that unit's rate.
-//   supp_synthesis_kernel  wave per stream, frames in order: pitch comb filter, band-gain
-//                          interpolation, inverse STFT, overlap-add, /32768, wet/dry mix.
+//   supp_resynth_kernel    wave per (frame, stream): pitch comb filter, band-gain interpolation, inverse
+//                          transform, synthesis window.
+//   supp_overlap_kernel    wave per stream, frames in order: overlap-add, /32768, smoothed wet/dry mix.
 #include <hip/hip_runtime.h>
 
 #include "af_fft_consts.h"
@@ -60,13 +61,16 @@ __device__ __forceinline__ float scale_for_model(float sample) {
   return scaled < -kLimit ? -kLimit : (scaled > kLimit ? kLimit : scaled);
 }
 
+// The pass is bound by memory latency (one row load per stream per tile), not by arithmetic, so a wave
+// owns only kPreGroup streams: more waves in flight, fewer dependent loads per wave.
+constexpr int kPreGroup = 8;
 extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
-  __shared__ float tile[64][65];
-  __shared__ float dry[64][65];
+  __shared__ float tile[64][kPreGroup + 1];
+  __shared__ float dry[64][kPreGroup + 1];
   const int lane = threadIdx.x;
-  const int s0 = blockIdx.x * 64;
+  const int s0 = blockIdx.x * kPreGroup;
   const int s = s0 + lane;
-  const bool valid = s < a.n_streams;
+  const bool valid = lane < kPreGroup && s < a.n_streams;
   const int sc = valid ? s : a.n_streams - 1;
   const int64_t NS = a.n_streams;
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
@@ -84,7 +88,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
     z2 = a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + sc];
   }
   // history: the previous 1728 model-input samples go in front of the window
-  for (int r = 0; r < 64; ++r) {
+  for (int r = 0; r < kPreGroup; ++r) {
     const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
 #pragma unroll 9
     for (int i = lane; i < kPitchBuf; i += 64)
@@ -96,12 +100,13 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
     // so the 64 row loads of a tile are independent and stay in flight together
     const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
     const int64_t col = a.frame0 * kRnnFrame + t0 + (lane < len ? lane : len - 1);
-#pragma unroll 16
-    for (int r = 0; r < 64; ++r) {
+#pragma unroll
+    for (int r = 0; r < kPreGroup; ++r) {
       const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
       tile[lane][r] = a.in[(int64_t)sr * a.stream_stride + col];
     }
     __syncthreads();
+    if (lane < kPreGroup)
     for (int t = 0; t < len; ++t) {
       float x = tile[t][lane];
       if (front) {
@@ -133,8 +138,8 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
       tile[t][lane] = y;
     }
     __syncthreads();
-#pragma unroll 16
-    for (int r = 0; r < 64; ++r) {
+#pragma unroll
+    for (int r = 0; r < kPreGroup; ++r) {
       const int sr = s0 + r;
       if (sr < a.n_streams && lane < len) {
         a.xh[(int64_t)sr * xh_stride + kPitchBuf + t0 + lane] = tile[lane][r];
@@ -946,24 +951,21 @@ struct SynthLds {
   float2 fa[kRnnWindow], fb[kRnnWindow];
   float2 X[kRnnFreq + 3], P[kRnnFreq + 3];
   float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], g[kRnnBands], graw[kRnnBands], r[kRnnBands], norm[kRnnBands];
-  float synth[kRnnFrame];
 };
 
-extern "C" __global__ __launch_bounds__(64, 2) void supp_synthesis_kernel(SuppArgs a, SuppTables tb) {
+// One wave per (frame, stream): comb filter, gains, inverse transform, synthesis window.  The 960 windowed
+// samples of the frame overwrite the cell's P spectrum (no longer needed: 481 complex = 962 floats >= 960).
+extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs a, SuppTables tb) {
   __shared__ SynthLds L;
   const int lane = threadIdx.x;
-  const int s = blockIdx.x;
-  float *st = a.state + (int64_t)s * SuppState::kCount;
-  for (int i = lane; i < kRnnFrame; i += 64) L.synth[i] = st[SuppState::kSynthMem + i];
+  const int64_t cell = blockIdx.x;
   for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
   for (int i = lane; i < 484; i += 64) L.band_of[i] = tb.band_of_bin[i];
   const FftLane fl = fft_lane_init(tb.twiddle, lane);
-  float smoothed = st[SuppState::kSmoothedStrength];
-  __syncthreads();
-  for (int f = 0; f < a.n_frames; ++f) {
-    const SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
-    const float2 *Xg = a.X + ((int64_t)f * a.n_streams + s) * kRnnFreq;
-    const float2 *Pg = a.P + ((int64_t)f * a.n_streams + s) * kRnnFreq;
+  {
+    const SuppFrameRec *rec = a.rec + cell;
+    const float2 *Xg = a.X + cell * kRnnFreq;
+    float2 *Pg = a.P + cell * kRnnFreq;
     for (int i = lane; i < kRnnFreq; i += 64) {
       L.X[i] = Xg[i];
       L.P[i] = Pg[i];
@@ -1017,39 +1019,50 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_synthesis_kernel(SuppAr
       L.fa[i] = i < kRnnFreq ? L.X[i] : make_float2(L.X[kRnnWindow - i].x, -L.X[kRnnWindow - i].y);
     __syncthreads();
     fft960_wave(L.fa, L.fb, fl, lane, 1.0f);
+    float *y = reinterpret_cast<float *>(Pg);
+    for (int i = lane; i < kRnnWindow; i += 64)
+      y[i] = L.fb[(kRnnWindow - i) % kRnnWindow].x * tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+  }
+}
+
+// One wave per stream, frames in order: overlap-add of the windowed frames, /32768, smoothed wet/dry mix.
+extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a) {
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x;
+  float *st = a.state + (int64_t)s * SuppState::kCount;
+  float smoothed = st[SuppState::kSmoothedStrength];
+  for (int f = 0; f < a.n_frames; ++f) {
+    const float *y = reinterpret_cast<const float *>(a.P + ((int64_t)f * a.n_streams + s) * kRnnFreq);
+    const float *prev = f == 0 ? st + SuppState::kSynthMem
+                               : reinterpret_cast<const float *>(a.P + ((int64_t)(f - 1) * a.n_streams + s) * kRnnFreq) + kRnnFrame;
     // wet/dry smoothing, rnnoise.rs:81-86 (once per frame)
     smoothed = a.strength * a.smoothing_coeff + smoothed * (1.0f - a.smoothing_coeff);
     const int64_t base = (int64_t)s * a.stream_stride + (a.frame0 + f) * kRnnFrame;
-    float carry[8];
-    int cnt = 0;
-    for (int i = lane; i < kRnnFrame; i += 64, ++cnt) {
-      const float lo = L.fb[(kRnnWindow - i) % kRnnWindow].x * tb.half_window[i];
-      const float hi = L.fb[kRnnWindow - (kRnnFrame + i)].x * tb.half_window[kRnnFrame - 1 - i];
-      float wet = (lo + L.synth[i]) / 32768.0f;
-      carry[cnt] = hi;
+#pragma unroll
+    for (int i = lane; i < kRnnFrame; i += 64) {
+      float wet = (y[i] + prev[i]) / 32768.0f;
       if (!a.raw_protocol && smoothed < 1.0f) {
         const float dry = (a.front_clamp || a.front_dc) ? a.out[base + i] : a.in[base + i];
         wet = (smoothed * wet) + ((1.0f - smoothed) * dry);
       }
       a.out[base + i] = wet;
     }
-    __syncthreads();
-    cnt = 0;
-    for (int i = lane; i < kRnnFrame; i += 64, ++cnt) L.synth[i] = carry[cnt];
-    __syncthreads();
   }
-  for (int i = lane; i < kRnnFrame; i += 64) st[SuppState::kSynthMem + i] = L.synth[i];
+  __syncthreads();  // frame 0 read the old synthesis memory above
+  const float *last = reinterpret_cast<const float *>(a.P + ((int64_t)(a.n_frames - 1) * a.n_streams + s) * kRnnFreq) + kRnnFrame;
+  for (int i = lane; i < kRnnFrame; i += 64) st[SuppState::kSynthMem + i] = last[i];
   if (lane == 0) st[SuppState::kSmoothedStrength] = smoothed;
 }
 
 // ============================================================================== launch
 hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
-  hipLaunchKernelGGL(supp_prefilter_kernel, dim3((a.n_streams + 63) / 64), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(supp_prefilter_kernel, dim3((a.n_streams + kPreGroup - 1) / kPreGroup), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(supp_spectrum_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
-  hipLaunchKernelGGL(supp_synthesis_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_resynth_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
