@@ -303,25 +303,37 @@ struct SpectrumLds {
   float frac[404];
 };
 
+// Frames handled by one wave of the frame-parallel kernels: the per-wave setup (twiddles, tables) is
+// a dozen dependent global loads, comparable to one transform, so it is shared by kFramesPerWave frames.
+constexpr int kFramesPerWave = 1;  // measured: 1 is fastest (the kernels are latency bound; more, shorter waves win)
+
 extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArgs a, SuppTables tb) {
   __shared__ SpectrumLds L;
   const int lane = threadIdx.x;
-  const int64_t cell = blockIdx.x;
-  const int f = (int)(cell / a.n_streams), s = (int)(cell % a.n_streams);
+  const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
+  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
-  const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
   const FftLane fl = fft_lane_init(tb.twiddle, lane);
   for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  for (int i = lane; i < kRnnWindow; i += 64) {
-    const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-    L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow + i] * w, 0.0f);
+  float win[15];
+#pragma unroll
+  for (int j = 0; j < 15; ++j) {
+    const int i = lane + 64 * j;
+    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
   }
-  __syncthreads();
-  fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
-  float2 *Xg = a.X + cell * kRnnFreq;
-  for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fb[i];
-  const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
-  if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
+  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+    const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 15; ++j) L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow + lane + 64 * j] * win[j], 0.0f);
+    __syncthreads();
+    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+    float2 *Xg = a.X + cell * kRnnFreq;
+    for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fb[i];
+    const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
+    if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
+  }
 }
 
 // ============================================================================== analysis, part 2
@@ -675,42 +687,55 @@ struct PitchSpecLds {
 extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppArgs a, SuppTables tb) {
   __shared__ PitchSpecLds L;
   const int lane = threadIdx.x;
-  const int64_t cell = blockIdx.x;
-  const int f = (int)(cell / a.n_streams), s = (int)(cell % a.n_streams);
+  const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
+  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
-  const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
-  SuppFrameRec *rec = a.rec + cell;
-  const int pitch_index = rec->pitch_index;
-  const bool silence = rec->silence != 0;
   const FftLane fl = fft_lane_init(tb.twiddle, lane);
   for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  const float2 *Xg = a.X + cell * kRnnFreq;
-  for (int i = lane; i < kRnnFreq; i += 64) L.X[i] = Xg[i];
-  for (int i = lane; i < kRnnWindow; i += 64) {
-    const float w = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-    L.fa[i] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + i] * w, 0.0f);
+  float win[15];
+#pragma unroll
+  for (int j = 0; j < 15; ++j) {
+    const int i = lane + 64 * j;
+    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
   }
-  __syncthreads();
-  fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
-  float2 *Pg = a.P + cell * kRnnFreq;
-  for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
-  const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
-  float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane);
-  if (lane < kRnnBands) {
-    const float ex = rec->Ex[lane];
-    exp_ = exp_ / sqrtf(.001f + ex * ep);
-    rec->Ep[lane] = ep;
-    rec->Exp[lane] = exp_;
-    L.Exp[lane] = exp_;
-  }
-  __syncthreads();
-  if (!silence && lane < 6) {  // dct(tmp, Exp), first six coefficients
-    float sum = 0;
-    for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * tb.dct[j * kRnnBands + lane];
-    float v = sum * sqrtf(2.0f / 22);
-    if (lane == 0) v -= 1.3f;
-    if (lane == 1) v -= 0.9f;
-    rec->feat[kRnnBands + 12 + lane] = v;
+  float dctcol[kRnnBands];
+#pragma unroll
+  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < 6 ? lane : 0)];
+  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+    const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
+    SuppFrameRec *rec = a.rec + cell;
+    const int pitch_index = rec->pitch_index;
+    const bool silence = rec->silence != 0;
+    const float2 *Xg = a.X + cell * kRnnFreq;
+    __syncthreads();
+    for (int i = lane; i < kRnnFreq; i += 64) L.X[i] = Xg[i];
+#pragma unroll
+    for (int j = 0; j < 15; ++j)
+      L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + lane + 64 * j] * win[j], 0.0f);
+    __syncthreads();
+    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+    float2 *Pg = a.P + cell * kRnnFreq;
+    for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
+    const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
+    float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane);
+    if (lane < kRnnBands) {
+      const float ex = rec->Ex[lane];
+      exp_ = exp_ / sqrtf(.001f + ex * ep);
+      rec->Ep[lane] = ep;
+      rec->Exp[lane] = exp_;
+      L.Exp[lane] = exp_;
+    }
+    __syncthreads();
+    if (!silence && lane < 6) {  // dct(tmp, Exp), first six coefficients
+      float sum = 0;
+#pragma unroll
+      for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * dctcol[j];
+      float v = sum * sqrtf(2.0f / 22);
+      if (lane == 0) v -= 1.3f;
+      if (lane == 1) v -= 0.9f;
+      rec->feat[kRnnBands + 12 + lane] = v;
+    }
   }
 }
 
@@ -958,11 +983,20 @@ struct SynthLds {
 extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs a, SuppTables tb) {
   __shared__ SynthLds L;
   const int lane = threadIdx.x;
-  const int64_t cell = blockIdx.x;
+  const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
+  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
   for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
   for (int i = lane; i < 484; i += 64) L.band_of[i] = tb.band_of_bin[i];
   const FftLane fl = fft_lane_init(tb.twiddle, lane);
-  {
+  float win[15];
+#pragma unroll
+  for (int j = 0; j < 15; ++j) {
+    const int i = lane + 64 * j;
+    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+  }
+  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+    __syncthreads();
     const SuppFrameRec *rec = a.rec + cell;
     const float2 *Xg = a.X + cell * kRnnFreq;
     float2 *Pg = a.P + cell * kRnnFreq;
@@ -1020,8 +1054,11 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs
     __syncthreads();
     fft960_wave(L.fa, L.fb, fl, lane, 1.0f);
     float *y = reinterpret_cast<float *>(Pg);
-    for (int i = lane; i < kRnnWindow; i += 64)
-      y[i] = L.fb[(kRnnWindow - i) % kRnnWindow].x * tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+      const int i = lane + 64 * j;
+      y[i] = L.fb[(kRnnWindow - i) % kRnnWindow].x * win[j];
+    }
   }
 }
 
@@ -1057,11 +1094,11 @@ extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a)
 // ============================================================================== launch
 hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
   hipLaunchKernelGGL(supp_prefilter_kernel, dim3((a.n_streams + kPreGroup - 1) / kPreGroup), dim3(64), 0, stream, a);
-  hipLaunchKernelGGL(supp_spectrum_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_spectrum_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
-  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
-  hipLaunchKernelGGL(supp_resynth_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_resynth_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
