@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/audioforge_mi.h"
@@ -66,6 +67,8 @@ struct af_engine {
   int last_launches = 0;
 
   af::ChainParams host_params{};
+  af::ChainParams uploaded{};   // what d_params currently holds
+  bool uploaded_valid = false;
   af::ChainParams *d_params = nullptr;
   double *d_st64 = nullptr;
   float *d_st32 = nullptr;
@@ -84,6 +87,9 @@ struct af_engine {
   int64_t io_capacity = 0;     // floats
   hipStream_t last_stream = nullptr;
   af::SuppressorHost supp;
+  hipStream_t aux_stream = nullptr;                      // chain launches while the suppressor fills the chip
+  std::vector<hipEvent_t> sync_events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
   int supp_window_frames = 50;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
@@ -250,6 +256,101 @@ void advance_crossfades(af_engine *e, int64_t n) {
   }
 }
 
+// One pass of the chain over a segment of samples for every stream: one launch, or the pre-pass + main
+// pair when the compressor's auto-makeup needs whole-block input power first (compressor.rs:710).
+// `params_stream` is where parameter uploads are ordered; `stream` is where the kernels run.
+int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
+                         int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
+                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/) {
+  af::ChainParams run = run_in;
+  const int cb = run.control_block;
+  const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
+  bool any_xf = false;
+  for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
+  const bool ring_fits = af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
+  const bool auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
+  int kernel = e->kernel;
+  if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
+  if (kernel == AF_KERNEL_PHASED && !ring_fits)
+    return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
+  if (auto_makeup && kernel != AF_KERNEL_PHASED)
+    return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
+  af::LaunchArgs a{};
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.in = in;
+  a.out = out;
+  a.stats = stats;
+  a.status = e->d_status;
+  a.params = e->d_params;
+  a.n_samples = n_samples;
+  a.stream_stride = stream_stride;
+  a.samples_before = samples_before;
+  a.n_streams = e->n_streams;
+  a.layout = layout;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (e->timing) {
+    AF_HIP(hipEventCreate(&t0));
+    AF_HIP(hipEventCreate(&t1));
+    AF_HIP(hipEventRecord(t0, stream));
+  }
+  if (kernel == AF_KERNEL_PHASED) {
+    // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
+    AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));
+    if (auto_makeup) {
+      if (rows > e->stats_pre_capacity) {
+        AF_HIP(hipStreamSynchronize(stream));
+        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
+        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
+        e->stats_pre_capacity = rows;
+      }
+      af::ChainParams pre = run, post = run;
+      pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser)) | af::kFlagPrePass;
+      post.flags &= ~(af::kFlagEq | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub | af::kFlagInputClamp);
+      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->uploaded_valid = false;  // d_params now holds the post-pass variant
+      AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
+      af::LaunchArgs a1 = a;
+      a1.params = e->d_params_pre;
+      a1.stats = e->d_stats_pre;
+      AF_HIP(af::launch_chain_ring(a1, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      af::LaunchArgs a2 = a;
+      a2.in = out;
+      a2.pre_stats = e->d_stats_pre;
+      a2.vad_prob = vad;
+      AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, true, stream));
+      AF_HIP(af::launch_merge_prepass_stats(stats, e->d_stats_pre, rows, stream));
+      e->last_launches += 3;
+    } else {
+      if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
+        e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
+        AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
+        AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+        e->uploaded_valid = true;
+      }
+      AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      e->last_launches += 1;
+    }
+  } else {
+    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
+      e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
+      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+      e->uploaded_valid = true;
+    }
+    AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
+    e->last_launches += 1;
+  }
+  if (e->timing) {
+    AF_HIP(hipEventRecord(t1, stream));
+    e->chain_ms_events.push_back({t0, t1});
+  }
+  advance_crossfades(e, n_samples);
+  return AF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -293,6 +394,9 @@ void af_engine_destroy(af_engine *e) {
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
   }
+  for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
+  for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->supp.d_blob || e->supp.d_state || e->supp.d_xh) {
     (void)hipSetDevice(e->device);
     e->supp.release_all();
@@ -511,12 +615,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipMalloc(&e->d_stats, sizeof(af::BlockStats) * rows));
     e->stats_capacity = rows;
   }
-  // ---- RNNoise suppressor ahead of the chain (realtime order, dsp_loop.rs:1222-1250,1521-1599)
-  af::ChainParams run = e->host_params;  // what the chain launch of THIS call uses
-  bool run_modified = false;
-  const float *chain_in = in;
-  bool any_xf = false;
-  for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
+  if ((e->host_params.flags & af::kFlagCompressor) && e->host_params.comp.auto_makeup_enabled && e->has_evidence &&
+      e->vad_blocks != blocks)
+    return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
+                (long long)blocks, (long long)e->vad_blocks);
   if (e->timing) {
     if (!e->ev_start) {
       AF_HIP(hipEventCreate(&e->ev_start));
@@ -525,131 +627,120 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     AF_HIP(hipEventRecord(e->ev_start, stream));
   }
-  af::LaunchArgs a{};
-  a.st64 = e->d_st64;
-  a.st32 = e->d_st32;
-  a.out = out;
-  a.status = e->d_status;
-  a.n_samples = n_samples;
-  a.stream_stride = stream_stride;
-  a.samples_before = e->samples_processed;
-  a.n_streams = e->n_streams;
-  a.layout = layout;
-  if (e->supp.enabled) {
-    if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
-    if (n_samples % af::kRnnFrame != 0)
-      return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
-                  af::kRnnFrame);
-    if (e->supp.weights_dirty) AF_HIP(e->supp.upload());
-    // the realtime front end (clamp + DC block + 80 Hz HP, routing.rs:802-843) runs inside the suppressor's
-    // own sample-serial pre-pass, so the chain launch afterwards must not repeat it
-    const uint32_t front = af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
-    const uint32_t front_flags = run.flags & front;
-    if (front_flags) {
-      run.flags &= ~(front | af::kFlagInputScrub);
-      run_modified = true;
-    }
-    const int64_t frames = n_samples / af::kRnnFrame;
-    const int window = (int)std::min<int64_t>(frames, e->supp_window_frames);
-    AF_HIP(e->supp.ensure_workspace(e->n_streams, window));
-    for (int64_t f0 = 0; f0 < frames; f0 += window) {
-      af::SuppArgs sa{};
-      sa.in = chain_in;
-      sa.out = out;
-      sa.xh = e->supp.d_xh;
-      sa.X = e->supp.d_X;
-      sa.P = e->supp.d_P;
-      sa.rec = e->supp.d_rec;
-      sa.state = e->supp.d_state;
-      sa.stream_stride = stream_stride;
-      sa.n_streams = e->n_streams;
-      sa.n_frames = (int)std::min<int64_t>(window, frames - f0);
-      sa.frame0 = f0;
-      sa.strength = e->supp.strength;
-      sa.smoothing_coeff = 1.0f - std::exp(-((480.0f / 48000.0f) / (15.0f / 1000.0f)));  // rnnoise.rs:45-51
-      sa.raw_protocol = e->supp.raw_protocol ? 1 : 0;
-      sa.front_clamp = (front_flags & af::kFlagInputClamp) ? 1 : 0;
-      sa.front_dc = (front_flags & af::kFlagDcBlock) ? 1 : 0;
-      sa.front_hp = (front_flags & af::kFlagPreHighpass) ? 1 : 0;
-      sa.hp_b0 = run.pre_hp.b0; sa.hp_b1 = run.pre_hp.b1; sa.hp_b2 = run.pre_hp.b2;
-      sa.hp_a1 = run.pre_hp.a1; sa.hp_a2 = run.pre_hp.a2;
-      sa.chain_st64 = e->d_st64;
-      sa.chain_st32 = e->d_st32;
-      sa.f64_pre_z1 = af::kPreZ1;
-      sa.f32_dc_x1 = af::kDcX1;
-      AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
-      e->last_launches += 7;
-    }
-    chain_in = out;
-  }
-  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, stream));
+  for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  e->chain_ms_events.clear();
 
-  const bool ring_fits = af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
-  const bool auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
-  int kernel = e->kernel;
-  if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
-  if (kernel == AF_KERNEL_PHASED && !ring_fits)
-    return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
-  if (auto_makeup && kernel != AF_KERNEL_PHASED)
-    return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
-  if (auto_makeup && e->has_evidence && e->vad_blocks != blocks)
-    return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
-                (long long)blocks, (long long)e->vad_blocks);
-  a.in = chain_in;
-  a.stats = e->d_stats;
-  a.params = e->d_params;
-  if (kernel == AF_KERNEL_PHASED) {
-    // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
-    AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
-    if (auto_makeup) {
-      // The compressor needs the RMS of each whole control block of ITS input before the block's first
-      // sample (compressor.rs:710).  Launch 1 runs the front end + EQ into `out` and leaves the block
-      // powers in its stats rows; launch 2 runs compressor -> limiter -> true peak over `out`.
-      if (rows > e->stats_pre_capacity) {
-        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
-        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
-        e->stats_pre_capacity = rows;
-      }
-      af::ChainParams pre = run, post = run;
-      pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser)) | af::kFlagPrePass;
-      post.flags &= ~(af::kFlagEq | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub | af::kFlagInputClamp);
-      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      e->params_dirty = true;  // d_params no longer holds host_params
-      AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
-      af::LaunchArgs a1 = a;
-      a1.params = e->d_params_pre;
-      a1.stats = e->d_stats_pre;
-      AF_HIP(af::launch_chain_ring(a1, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
-      af::LaunchArgs a2 = a;
-      a2.in = out;
-      a2.pre_stats = e->d_stats_pre;
-      a2.vad_prob = e->has_evidence ? e->d_vad : nullptr;
-      AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, true, stream));
-      AF_HIP(af::launch_merge_prepass_stats(e->d_stats, e->d_stats_pre, rows, stream));
-      e->last_launches += 3;
-    } else {
-      if (e->params_dirty || run_modified) {
-        AF_HIP(hipMemcpyAsync(e->d_params, &run, sizeof run, hipMemcpyHostToDevice, stream));
-        AF_HIP(hipStreamSynchronize(stream));  // `run` is a stack copy
-        e->params_dirty = run_modified;
-      }
-      AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
-      e->last_launches += 1;
+  if (!e->supp.enabled) {
+    int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
+                                  e->d_stats, e->has_evidence ? e->d_vad : nullptr, stream, stream);
+    if (rc) return rc;
+    if (e->timing) {
+      AF_HIP(hipEventRecord(e->ev_mid, stream));  // no suppressor: everything is chain time
+      AF_HIP(hipEventRecord(e->ev_stop, stream));
     }
-  } else {
-    if (e->params_dirty || run_modified) {
-      AF_HIP(hipMemcpyAsync(e->d_params, &run, sizeof run, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      e->params_dirty = run_modified;
+    e->samples_processed += n_samples;
+    return AF_OK;
+  }
+
+  // ---- RNNoise suppressor ahead of the chain (realtime order, dsp_loop.rs:1222-1250,1521-1599).
+  // The call is cut into windows of frames.  Window w's suppressor kernels (which fill the whole chip) run
+  // on the caller's stream; the chain launch over the same window (64 streams per workgroup, a quarter of
+  // the CUs at batch 4096) runs on a second stream behind an event, so it overlaps window w+1's suppressor.
+  if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
+  if (n_samples % af::kRnnFrame != 0)
+    return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
+                af::kRnnFrame);
+  if (e->supp.weights_dirty) AF_HIP(e->supp.upload());
+  af::ChainParams run = e->host_params;
+  bool run_modified = false;
+  const uint32_t front = af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
+  const uint32_t front_flags = run.flags & front;
+  if (front_flags) {
+    // the realtime front end (clamp + DC block + 80 Hz HP, routing.rs:802-843) runs inside the suppressor's
+    // own sample-serial pre-pass, so the chain launches must not repeat it
+    run.flags &= ~(front | af::kFlagInputScrub);
+    run_modified = true;
+  }
+  const int64_t frames = n_samples / af::kRnnFrame;
+  // a window must hold whole control blocks, or block boundaries (hence per-block semantics) would move
+  int64_t unit = 1;
+  while ((unit * af::kRnnFrame) % cb != 0) ++unit;
+  int64_t window = std::max<int64_t>(unit, (e->supp_window_frames / unit) * unit);
+  const bool windows_align = frames % unit == 0 || frames <= window;
+  if (!windows_align) window = frames;  // ragged tail: one window (workspace permitting)
+  window = std::min<int64_t>(window, frames);
+  AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
+  if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+  int64_t blocks_done = 0;
+  size_t ev_index = 0;
+  auto next_event = [&](hipEvent_t *out_ev) -> int {
+    if (ev_index == e->sync_events.size()) {
+      hipEvent_t ev;
+      AF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      e->sync_events.push_back(ev);
     }
-    AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
-    e->last_launches += 1;
+    *out_ev = e->sync_events[ev_index++];
+    return AF_OK;
+  };
+  {  // the chain stream starts after whatever the caller queued before this call
+    hipEvent_t ev;
+    if (int rc = next_event(&ev)) return rc;
+    AF_HIP(hipEventRecord(ev, stream));
+    AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
+  }
+  for (int64_t f0 = 0; f0 < frames; f0 += window) {
+    const int64_t nf = std::min<int64_t>(window, frames - f0);
+    af::SuppArgs sa{};
+    sa.in = in;
+    sa.out = out;
+    sa.xh = e->supp.d_xh;
+    sa.X = e->supp.d_X;
+    sa.P = e->supp.d_P;
+    sa.rec = e->supp.d_rec;
+    sa.state = e->supp.d_state;
+    sa.stream_stride = stream_stride;
+    sa.n_streams = e->n_streams;
+    sa.n_frames = (int)nf;
+    sa.frame0 = f0;
+    sa.strength = e->supp.strength;
+    sa.smoothing_coeff = 1.0f - std::exp(-((480.0f / 48000.0f) / (15.0f / 1000.0f)));  // rnnoise.rs:45-51
+    sa.raw_protocol = e->supp.raw_protocol ? 1 : 0;
+    sa.front_clamp = (front_flags & af::kFlagInputClamp) ? 1 : 0;
+    sa.front_dc = (front_flags & af::kFlagDcBlock) ? 1 : 0;
+    sa.front_hp = (front_flags & af::kFlagPreHighpass) ? 1 : 0;
+    sa.hp_b0 = run.pre_hp.b0; sa.hp_b1 = run.pre_hp.b1; sa.hp_b2 = run.pre_hp.b2;
+    sa.hp_a1 = run.pre_hp.a1; sa.hp_a2 = run.pre_hp.a2;
+    sa.chain_st64 = e->d_st64;
+    sa.chain_st32 = e->d_st32;
+    sa.f64_pre_z1 = af::kPreZ1;
+    sa.f32_dc_x1 = af::kDcX1;
+    if (f0 > 0) {  // the workspace is reused: this window's kernels follow the previous window's on `stream` anyway
+    }
+    AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
+    e->last_launches += 7;
+    hipEvent_t ev;
+    if (int rc = next_event(&ev)) return rc;
+    AF_HIP(hipEventRecord(ev, stream));
+    AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
+    const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
+    const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
+    int rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
+                                  e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream,
+                                  stream);
+    if (rc) return rc;
+    run = e->host_params;  // crossfade bookkeeping may have moved on
+    if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
+    blocks_done += (seg_n + cb - 1) / cb;
+  }
+  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, stream));  // last suppressor kernel done
+  {
+    hipEvent_t ev;
+    if (int rc = next_event(&ev)) return rc;
+    AF_HIP(hipEventRecord(ev, e->aux_stream));
+    AF_HIP(hipStreamWaitEvent(stream, ev, 0));
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
-  advance_crossfades(e, n_samples);
   return AF_OK;
 }
 
@@ -716,8 +807,13 @@ int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_m
   float t = 0.0f;
   AF_HIP(hipEventElapsedTime(&t, e->ev_start, e->ev_mid));
   *suppressor_ms = (double)t;
-  AF_HIP(hipEventElapsedTime(&t, e->ev_mid, e->ev_stop));
-  *chain_ms = (double)t;
+  double chain = 0.0;
+  for (auto &pr : e->chain_ms_events) {
+    AF_HIP(hipEventSynchronize(pr.second));
+    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    chain += (double)t;
+  }
+  *chain_ms = chain;  // summed over the chain launches of the call (they may overlap suppressor kernels)
   return AF_OK;
 }
 
