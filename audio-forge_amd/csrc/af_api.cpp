@@ -22,7 +22,11 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
-hipError_t launch_merge_prepass_stats(BlockStats *rows, const BlockStats *pre, int64_t n, hipStream_t stream);
+hipError_t launch_merge_side_stats(BlockStats *rows, const BlockStats *input_rows, const BlockStats *deesser_rows,
+                                   int64_t n, hipStream_t stream);
+hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32, const float *in, float *out,
+                          BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
+                          int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
@@ -77,6 +81,10 @@ struct af_engine {
   af::BlockStats *d_stats_pre = nullptr;   // rows of the pre-pass launch (auto-makeup)
   int64_t stats_pre_capacity = 0;
   af::ChainParams *d_params_pre = nullptr;
+  af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
+  af::ChainParams *d_params_de = nullptr;  // the de-esser pass reads the unedited parameter block
+  af::ChainParams uploaded_de{};
+  bool uploaded_de_valid = false;
   double *d_vad = nullptr;                 // [blocks][streams] speech posteriors for the next call
   int64_t vad_capacity = 0, vad_blocks = 0;
   double vad_reliability = 0.0, noise_floor_db = 0.0, live_noise_reliability = 0.0;
@@ -143,6 +151,7 @@ void export_params(af_engine *e) {
   o.comp.live_noise_reliability = e->live_noise_reliability;
   o.comp.has_evidence = e->has_evidence ? 1 : 0;
   o.lim = p.limiter.params();
+  o.deesser = p.deesser.params();
   // block_processor.rs:150-151: the TP ceiling follows the limiter ceiling on every block
   af::TruePeakProto tp = p.tp_limiter;
   tp.set_ceiling_linear(std::pow(10.0f, (float)p.limiter.ceiling_db / 20.0f));
@@ -184,6 +193,11 @@ int upload_initial_state(af_engine *e) {
   v64[af::kCompSmoothedMakeup] = c.smoothed_makeup_gain;
   v64[af::kCompCurrentLufs] = -100.0;
   v64[af::kLimGain] = 1.0;
+  for (int i = 0; i < 3; ++i) {  // the dynamic EQ's coefficients are per-stream state (deesser.rs:536-538)
+    const af::BiquadCoef &c = e->host_params.deesser.bands[i].dynamic_eq.active;
+    double *d = &v64[af::kDeBand0 + i * af::kDeBandStride + 6];
+    d[0] = c.b0; d[1] = c.b1; d[2] = c.b2; d[3] = c.a1; d[4] = c.a2;
+  }
   v32[af::kTpGain] = 1.0f;
   // broadcast: every stream starts from the prototype
   std::vector<double> plane64((size_t)n64 * B);
@@ -198,7 +212,6 @@ int upload_initial_state(af_engine *e) {
 int ensure_started(af_engine *e) {
   AF_HIP(hipSetDevice(e->device));
   if (!e->started) {
-    if (e->proto.deesser_enabled) return fail(AF_ERR_UNSUPPORTED, "the de-esser stage is not built for the GPU yet");
     if (e->proto.limiter_enabled && e->proto.limiter.lookahead_samples > af::kLdsLookaheadMax)
       return fail(AF_ERR_UNSUPPORTED, "limiter lookahead of %d samples exceeds the LDS-resident ring (%d)",
                   e->proto.limiter.lookahead_samples, af::kLdsLookaheadMax);
@@ -212,6 +225,7 @@ int ensure_started(af_engine *e) {
     }
     if (!e->d_params) AF_HIP(hipMalloc(&e->d_params, sizeof(af::ChainParams)));
     if (!e->d_params_pre) AF_HIP(hipMalloc(&e->d_params_pre, sizeof(af::ChainParams)));
+    if (!e->d_params_de) AF_HIP(hipMalloc(&e->d_params_de, sizeof(af::ChainParams)));
     if (!e->d_status) {
       AF_HIP(hipMalloc(&e->d_status, sizeof(int32_t)));
       AF_HIP(hipMemset(e->d_status, 0, sizeof(int32_t)));
@@ -241,8 +255,16 @@ int check_device_status(af_engine *e) {
 // after a launch of n samples: advance the (stream-uniform) crossfade counters
 void advance_crossfades(af_engine *e, int64_t n) {
   af::ChainParams &o = e->host_params;
-  for (int k = 0; k < o.n_eq_sections; ++k) {
-    af::SectionParams &sp = o.eq[k];
+  std::vector<af::SectionParams *> sections;
+  for (int k = 0; k < o.n_eq_sections; ++k) sections.push_back(&o.eq[k]);
+  if (o.flags & af::kFlagDeesser)
+    for (auto &b : o.deesser.bands) {
+      sections.push_back(&b.detector_hp);
+      sections.push_back(&b.detector_lp);
+      sections.push_back(&b.dynamic_eq);
+    }
+  for (af::SectionParams *spp : sections) {
+    af::SectionParams &sp = *spp;
     if (sp.xf_remaining > 0) {
       if (n >= sp.xf_remaining) {  // promote_pending_coefficients, biquad.rs:276-286
         sp.active = sp.pending;
@@ -275,6 +297,12 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
   if (auto_makeup && kernel != AF_KERNEL_PHASED)
     return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
+  const bool deesser = (run.flags & af::kFlagDeesser) != 0;
+  const bool eq_first = (run.flags & af::kFlagEqBeforeDeesser) != 0;
+  const uint32_t front_flags = af::kFlagInputScrub | af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
+  const bool two_pass = auto_makeup || (deesser && eq_first);
+  if (two_pass && kernel != AF_KERNEL_PHASED)
+    return fail(AF_ERR_UNSUPPORTED, "EQ-before-de-esser order is only built around the token-ring kernel");
   af::LaunchArgs a{};
   a.st64 = e->d_st64;
   a.st32 = e->d_st32;
@@ -294,19 +322,42 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     AF_HIP(hipEventCreate(&t1));
     AF_HIP(hipEventRecord(t0, stream));
   }
+  if ((two_pass || deesser) && rows > e->stats_pre_capacity) {
+    AF_HIP(hipStreamSynchronize(stream));
+    if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
+    if (e->d_stats_de) AF_HIP(hipFree(e->d_stats_de));
+    AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
+    AF_HIP(hipMalloc(&e->d_stats_de, sizeof(af::BlockStats) * rows));
+    e->stats_pre_capacity = rows;
+  }
+  const af::BlockStats *input_rows = nullptr;  // where the block input statistics end up when a side pass saw the input
+  if (deesser) {
+    // the de-esser pass reads the unmodified parameter block (its own copy: the chain kernels get edited flags)
+    if (!e->uploaded_de_valid || std::memcmp(&e->uploaded_de, &run_in, sizeof run_in) != 0) {
+      e->uploaded_de = run_in;
+      AF_HIP(hipMemcpyAsync(e->d_params_de, &e->uploaded_de, sizeof run_in, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->uploaded_de_valid = true;
+    }
+    AF_HIP(hipMemsetAsync(e->d_stats_de, 0, sizeof(af::BlockStats) * rows, stream));
+    if (!eq_first) {
+      // routing.rs: pre-filter -> de-esser -> EQ ...: this pass takes the front end with it
+      AF_HIP(af::launch_deesser(e->d_params_de, e->d_st64, e->d_st32, in, out, e->d_stats_de, n_samples, stream_stride,
+                                e->n_streams, layout, true, false, stream));
+      e->last_launches += 1;
+      a.in = out;
+      run.flags &= ~front_flags;
+      input_rows = e->d_stats_de;
+    }
+    run.flags &= ~af::kFlagDeesser;
+  }
   if (kernel == AF_KERNEL_PHASED) {
     // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
     AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));
-    if (auto_makeup) {
-      if (rows > e->stats_pre_capacity) {
-        AF_HIP(hipStreamSynchronize(stream));
-        if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
-        AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
-        e->stats_pre_capacity = rows;
-      }
+    if (two_pass) {
       af::ChainParams pre = run, post = run;
-      pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser)) | af::kFlagPrePass;
-      post.flags &= ~(af::kFlagEq | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub | af::kFlagInputClamp);
+      pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter)) | af::kFlagPrePass;
+      post.flags &= ~(af::kFlagEq | front_flags);
       AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
       AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
       AF_HIP(hipStreamSynchronize(stream));
@@ -316,13 +367,23 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       a1.params = e->d_params_pre;
       a1.stats = e->d_stats_pre;
       AF_HIP(af::launch_chain_ring(a1, pre.n_eq_sections, pre.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      if (!input_rows) input_rows = e->d_stats_pre;
+      const af::BlockStats *power_rows = e->d_stats_pre;
+      if (deesser && eq_first) {
+        // ... -> EQ -> de-esser -> compressor: the compressor-input block power is the de-esser's output power
+        AF_HIP(af::launch_deesser(e->d_params_de, e->d_st64, e->d_st32, out, out, e->d_stats_de, n_samples, stream_stride,
+                                  e->n_streams, layout, false, auto_makeup, stream));
+        e->last_launches += 1;
+        power_rows = e->d_stats_de;
+      }
       af::LaunchArgs a2 = a;
       a2.in = out;
-      a2.pre_stats = e->d_stats_pre;
-      a2.vad_prob = vad;
-      AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, true, stream));
-      AF_HIP(af::launch_merge_prepass_stats(stats, e->d_stats_pre, rows, stream));
-      e->last_launches += 3;
+      if (auto_makeup) {
+        a2.pre_stats = power_rows;
+        a2.vad_prob = vad;
+      }
+      AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, auto_makeup, stream));
+      e->last_launches += 2;
     } else {
       if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
         e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
@@ -341,6 +402,10 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       e->uploaded_valid = true;
     }
     AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
+    e->last_launches += 1;
+  }
+  if (input_rows || deesser) {
+    AF_HIP(af::launch_merge_side_stats(stats, input_rows, deesser ? e->d_stats_de : nullptr, rows, stream));
     e->last_launches += 1;
   }
   if (e->timing) {
@@ -387,6 +452,8 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_stats);
     (void)hipFree(e->d_stats_pre);
     (void)hipFree(e->d_params_pre);
+    (void)hipFree(e->d_params_de);
+    (void)hipFree(e->d_stats_de);
     (void)hipFree(e->d_vad);
     (void)hipFree(e->d_status);
     (void)hipFree(e->d_io);

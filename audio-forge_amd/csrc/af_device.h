@@ -70,15 +70,18 @@ struct TruePeakParams {
   float ceiling_linear, release_coeff;
 };
 
-// dsp/deesser.rs:88-107 (+ per band static data)
+// dsp/deesser.rs:34-107: three sibilance bands, each a detector (HP -> LP) and a dynamic peaking EQ.
+// The detector filters and the dynamic EQ are `Biquad`s and carry the usual coefficient crossfade
+// (set_low_cut_hz / set_high_cut_hz schedule one); the dynamic EQ recomputes its RBJ peaking coefficients
+// whenever the smoothed reduction moved by more than 0.001 dB (set_gain_db_immediate, deesser.rs:536-538).
 struct DeEsserBandParams {
-  BiquadCoef detector_hp, detector_lp;
-  double dyn_sin_omega, dyn_cos_omega, dyn_alpha;  // dynamic_eq: fixed centre & Q
+  SectionParams detector_hp, detector_lp, dynamic_eq;
+  double dyn_cos_omega, dyn_alpha;  // target centre / Q of the dynamic EQ (deesser.rs:263-272)
 };
 struct DeEsserParams {
   double attack_coeff, release_coeff, detector_attack_coeff, detector_release_coeff;
   double max_reduction_db, threshold_db, ratio, auto_amount;
-  double baseline_fall, baseline_rise, baseline_inactive;
+  double baseline_fall, baseline_rise, baseline_inactive;  // tc(13.88 / 34.72 / 20.82 ms), deesser.rs:274-287
   int32_t auto_enabled, pad;
   DeEsserBandParams bands[3];
 };
@@ -119,9 +122,10 @@ enum F64Field : int {
   kCompActivityScore, kCompActivityReliability, kCompCurrentLufs,
   kLimGain,
   kDeBroadbandEnv, kDeCurrentReduction, kDeConfidence,
-  // per de-esser band (x3): env, confidence, baseline, reduction, dyn gain, hp z1 z2, lp z1 z2, dyn z1 z2
+  // per de-esser band (x3): env, confidence, baseline, reduction, dyn gain_db, dyn crossfade-cancelled flag,
+  // the dynamic EQ's five live coefficients, then z1 z2 pz1 pz2 for detector_hp, detector_lp, dynamic_eq
   kDeBand0,
-  kDeBandStride = 11,
+  kDeBandStride = 23,
   kEqBase = kDeBand0 + 3 * kDeBandStride,  // then 4 per section: z1 z2 pz1 pz2
   kF64Fixed = kEqBase
 };

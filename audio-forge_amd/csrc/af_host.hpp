@@ -522,6 +522,32 @@ struct DeEsserProto {  // dsp/deesser.rs:109-353
   void set_attack_ms(double v) { attack_coeff = time_constant_to_coeff(clampd(v, 0.1, 50.0), sample_rate); }
   void set_release_ms(double v) { release_coeff = time_constant_to_coeff(clampd(v, 5.0, 500.0), sample_rate); }
   void set_max_reduction_db(double v) { max_reduction_db = clampd(v, 0.0, 24.0); }
+
+  DeEsserParams params() const {
+    DeEsserParams p{};
+    p.attack_coeff = attack_coeff;
+    p.release_coeff = release_coeff;
+    p.detector_attack_coeff = detector_attack_coeff;
+    p.detector_release_coeff = detector_release_coeff;
+    p.max_reduction_db = max_reduction_db;
+    p.threshold_db = threshold_db;
+    p.ratio = ratio;
+    p.auto_amount = auto_amount;
+    p.baseline_fall = time_constant_to_coeff(13.88, sample_rate);
+    p.baseline_rise = time_constant_to_coeff(34.72, sample_rate);
+    p.baseline_inactive = time_constant_to_coeff(20.82, sample_rate);
+    p.auto_enabled = auto_enabled;
+    for (int i = 0; i < 3; ++i) {
+      p.bands[i].detector_hp = bands[i].detector_hp.section();
+      p.bands[i].detector_lp = bands[i].detector_lp.section();
+      p.bands[i].dynamic_eq = bands[i].dynamic_eq.section();
+      const BiquadProto &d = bands[i].dynamic_eq;
+      const double omega = 2.0 * kPi * d.frequency / d.sample_rate;
+      p.bands[i].dyn_cos_omega = std::cos(omega);
+      p.bands[i].dyn_alpha = std::sin(omega) / (2.0 * std::fmax(d.q, 1e-6));
+    }
+    return p;
+  }
 };
 
 // ------------------------------------------------------------------- the whole prototype

@@ -872,19 +872,6 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 #undef L32
 }
 
-// After a two-launch run the chain-input statistics live in the pre-pass rows: fold them in.
-__global__ void merge_prepass_stats_kernel(BlockStats *rows, const BlockStats *pre, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    rows[i].input_square_sum = pre[i].input_square_sum;
-    rows[i].input_sample_peak = pre[i].input_sample_peak;
-  }
-}
-hipError_t launch_merge_prepass_stats(BlockStats *rows, const BlockStats *pre, int64_t n, hipStream_t stream) {
-  hipLaunchKernelGGL(merge_prepass_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, pre, n);
-  return hipGetLastError();
-}
-
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade) {
   return ring_lds_bytes(n_sections, lookahead_samples, crossfade);
 }
