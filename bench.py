@@ -153,6 +153,7 @@ def main() -> None:
         os.environ["AF_KERNEL_VARIANT"] = args.variant
     import mic_eq_mi
     from mic_eq_mi import mic_eq_core as core
+    from mic_eq_mi import sharding
 
     if not mic_eq_mi.CORE_AVAILABLE:
         raise SystemExit("libaudioforge_mi.so is missing; run __graft_entry__.build()")
@@ -160,7 +161,9 @@ def main() -> None:
     n_blocks = int(round(args.seconds * 100))
     n = n_blocks * 480
     streams = args.streams
-    x = synth_batch(streams, n_blocks, rank * streams, device)
+    first_stream, shard = sharding.stream_shard(world * streams, rank, world)  # weak scaling: B/G fixed per GPU
+    assert shard == streams
+    x = synth_batch(streams, n_blocks, first_stream, device)
     y = torch.empty_like(x)
     torch.cuda.synchronize()
 
@@ -200,15 +203,10 @@ def main() -> None:
 
     # the one collective: metric reduction over ranks (RCCL over xGMI when world > 1)
     rows = engine.block_stats()
-    metrics_sum = torch.tensor([float(rows["output_square_sum"].sum()), float(rows["input_square_sum"].sum()),
-                                float(rows["true_peak_limited_events"].sum())], dtype=torch.float64, device=device)
-    metrics_max = torch.tensor([float(rows["output_sample_peak"].max()), float(rows["output_true_peak"].max()),
-                                float(rows["compressor_gain_reduction_db"].max()), elapsed], dtype=torch.float64, device=device)
-    if distributed:
-        dist.all_reduce(metrics_sum, op=dist.ReduceOp.SUM)
-        dist.all_reduce(metrics_max, op=dist.ReduceOp.MAX)
-    elapsed_max = float(metrics_max[3])
-    total_frames = world * streams * n * args.steps
+    sums, maxes = sharding.local_metrics(rows, streams * n * args.steps, elapsed)
+    merged = sharding.reduce_metrics(sums, maxes, device)
+    elapsed_max = merged["elapsed_s"]
+    total_frames = int(merged["samples"])
     value = total_frames / elapsed_max
 
     kernel_name = "chain_lane_kernel" if args.variant == "lane" or args.kernel == 1 else "chain_ring_kernel<" + (args.variant[5:] if args.variant.startswith("ring-") else "16x4") + ">"
@@ -248,8 +246,10 @@ def main() -> None:
             },
             "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),
                          "all_kernels": float(np.mean(kernel_ms))},
-            "checks": {"output_rms": float(np.sqrt(float(metrics_sum[0]) / (world * streams * n))),
-                       "output_sample_peak": float(metrics_max[0]), "max_compressor_gr_db": float(metrics_max[2])},
+            "checks": {"output_rms": float(np.sqrt(merged["output_square_sum"] / (world * streams * n))),
+                       "output_sample_peak": merged["output_sample_peak"], "output_true_peak": merged["output_true_peak"],
+                       "max_compressor_gr_db": merged["compressor_gain_reduction_db"],
+                       "true_peak_limited_blocks": int(merged["true_peak_limited_events"])},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.seconds, full)
