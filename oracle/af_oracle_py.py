@@ -413,3 +413,39 @@ def prefilter(audio, sample_rate: float = 48000.0) -> np.ndarray:
     out = np.ascontiguousarray(audio, dtype=np.float32).copy()
     L.afo_prefilter_process_block(C.byref(pre), _fptr(out), out.size, 1)
     return out
+
+
+RESAMPLER_WINDOWS = {"blackman_harris": 0, "blackman_harris_squared": 1, "blackman": 2, "blackman_squared": 3,
+                     "hann": 4, "hann_squared": 5}
+
+
+def simulate_product_resampler(samples, input_rate: int, output_rate: int, chunk_size: int = 1024,
+                               sinc_len: int | None = None, window: str | None = None, f_cutoff: float = 0.0):
+    """resampling.rs:179-261 over the rubato restatement (oracle/af_resampler.c; sample parity unpinned).
+    Returns (output ndarray f64, delay, expected_frames, blocks)."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.afo_simulate_product_resampler.restype = C.c_int64
+    L.afo_simulate_product_resampler.argtypes = [dp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_int,
+                                                 C.c_float, dp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_size_t)]
+    x = np.ascontiguousarray(samples, dtype=np.float64)
+    sinc_len = 128 if sinc_len is None else int(sinc_len)
+    win = RESAMPLER_WINDOWS["blackman" if window is None else window]
+    ratio = output_rate / input_rate
+    cap = int((x.size + 4 * chunk_size + 2 * sinc_len) * ratio * 1.01) + 4096
+    out = np.zeros(cap, dtype=np.float64)
+    delay, expected, blocks = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    n = L.afo_simulate_product_resampler(x.ctypes.data_as(dp), x.size, int(input_rate), int(output_rate), int(chunk_size),
+                                         sinc_len, win, float(f_cutoff), out.ctypes.data_as(dp), cap, C.byref(delay),
+                                         C.byref(expected), C.byref(blocks))
+    if n < 0:
+        raise RuntimeError(f"output capacity too small ({-n} frames needed)")
+    return out[:n], int(delay.value), int(expected.value), int(blocks.value)
+
+
+def resampler_calculate_cutoff(sinc_len: int = 128, window: str = "blackman") -> float:
+    L = lib()
+    L.afo_resampler_calculate_cutoff.restype = C.c_float
+    L.afo_resampler_calculate_cutoff.argtypes = [C.c_size_t, C.c_int]
+    return float(L.afo_resampler_calculate_cutoff(int(sinc_len), RESAMPLER_WINDOWS[window]))
