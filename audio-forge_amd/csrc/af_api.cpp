@@ -14,6 +14,7 @@
 #include "../../include/audioforge_mi.h"
 #include "af_device.h"
 #include "af_host.hpp"
+#include "af_resampler_host.hpp"
 #include "af_suppressor_host.hpp"
 
 namespace af {
@@ -24,6 +25,10 @@ hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahe
                              bool auto_makeup, hipStream_t stream);
 hipError_t launch_merge_side_stats(BlockStats *rows, const BlockStats *input_rows, const BlockStats *deesser_rows,
                                    int64_t n, hipStream_t stream);
+hipError_t launch_resample(const double *in, double *out, const ResamplePos *pos, const double *table, int64_t n_in,
+                           int64_t n_out, int64_t in_stride, int64_t out_stride, int32_t n_streams, int32_t sinc_len,
+                           double ratio, hipStream_t stream);
+int resample_segment_outputs(double ratio, int sinc_len);
 hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32, const float *in, float *out,
                           BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
@@ -931,6 +936,191 @@ int af_eq_magnitude_response_v2(const double *freqs, size_t n, const af_eq_band_
 int af_engine_eq_magnitude_response(const af_engine *e, const double *freqs, size_t n, double *out_db) {
   if (!e || (!freqs && n) || (!out_db && n)) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
   for (size_t i = 0; i < n; ++i) out_db[i] = e->proto.eq.magnitude_db(freqs[i]);
+  return AF_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Product resampler (rust-core/src/audio/processor/resampling.rs:140-261)
+struct af_resampler {
+  af::ResamplePlan plan;
+  int device = 0;
+  std::vector<af::ResamplePos> pos;
+  int64_t planned_n_in = -1, planned_n_out = 0, planned_blocks = 0, uploaded_n_in = -1;
+  double *d_table = nullptr;
+  af::ResamplePos *d_pos = nullptr;
+  int64_t pos_capacity = 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  int64_t in_capacity = 0, out_capacity = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+namespace {
+// host only: replay the reference's chunk loop for n_in frames
+int resampler_plan(af_resampler *r, int64_t n_in) {
+  if (r->planned_n_in == n_in) return AF_OK;
+  r->planned_n_out = r->plan.positions(n_in, r->pos, &r->planned_blocks);
+  r->planned_n_in = n_in;
+  r->uploaded_n_in = -1;
+  return AF_OK;
+}
+// device side of the plan: coefficient table (once) and the position records of the current plan
+int resampler_upload(af_resampler *r) {
+  AF_HIP(hipSetDevice(r->device));
+  if (!r->d_table) {
+    AF_HIP(hipMalloc(&r->d_table, sizeof(double) * r->plan.table.size()));
+    AF_HIP(hipMemcpy(r->d_table, r->plan.table.data(), sizeof(double) * r->plan.table.size(), hipMemcpyHostToDevice));
+  }
+  if (r->uploaded_n_in == r->planned_n_in) return AF_OK;
+  if (r->planned_n_out > r->pos_capacity) {
+    if (r->d_pos) AF_HIP(hipFree(r->d_pos));
+    r->d_pos = nullptr;
+    AF_HIP(hipMalloc(&r->d_pos, sizeof(af::ResamplePos) * r->planned_n_out));
+    r->pos_capacity = r->planned_n_out;
+  }
+  if (r->planned_n_out > 0)
+    AF_HIP(hipMemcpy(r->d_pos, r->pos.data(), sizeof(af::ResamplePos) * r->planned_n_out, hipMemcpyHostToDevice));
+  r->uploaded_n_in = r->planned_n_in;
+  return AF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int af_resampler_calculate_cutoff(int32_t sinc_len, int32_t window, float *out) {
+  if (!out) return fail(AF_ERR_INVALID_ARGUMENT, "out is null");
+  if (window < 0 || window > af::kWinHann2) return fail(AF_ERR_INVALID_ARGUMENT, "unsupported resampler window %d", window);
+  *out = af::resample_calculate_cutoff(sinc_len, window);
+  return AF_OK;
+}
+
+int af_resampler_create(uint32_t input_rate, uint32_t output_rate, int64_t chunk_size, int32_t sinc_len, int32_t window,
+                        int32_t device, af_resampler **out) {
+  if (!out) return fail(AF_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  // the argument checks of simulate_product_resampler, resampling.rs:187-214
+  if (input_rate == 0 || output_rate == 0) return fail(AF_ERR_INVALID_ARGUMENT, "sample rates must be positive");
+  if (chunk_size < 1 || chunk_size > 1024) return fail(AF_ERR_INVALID_ARGUMENT, "chunk_size must be between 1 and 1024");
+  if (sinc_len < 32 || sinc_len > 2048 || (sinc_len & (sinc_len - 1)) != 0)
+    return fail(AF_ERR_INVALID_ARGUMENT, "sinc_len must be a power of two between 32 and 2048");
+  if (window < 0 || window > af::kWinHann2) return fail(AF_ERR_INVALID_ARGUMENT, "unsupported resampler window %d", window);
+  if (device < 0) return fail(AF_ERR_INVALID_ARGUMENT, "device must be >= 0");
+  const double ratio = (double)output_rate / (double)input_rate;
+  if (chunk_size <= (int64_t)sinc_len + 1 + (int64_t)std::ceil(1.0 / ratio))
+    return fail(AF_ERR_UNSUPPORTED, "chunk_size %lld is too short for sinc_len %d: the reference's chunk loop would produce no frames",
+                (long long)chunk_size, sinc_len);
+  if (af::resample_segment_outputs(ratio, sinc_len) == 0)
+    return fail(AF_ERR_UNSUPPORTED, "sinc_len %d at ratio %.4f needs a longer input span than the LDS tile holds", sinc_len, ratio);
+  af_resampler *r = new af_resampler();
+  r->device = device;
+  r->plan.build(input_rate, output_rate, chunk_size, sinc_len, window);
+  *out = r;
+  return AF_OK;
+}
+
+void af_resampler_destroy(af_resampler *r) {
+  if (!r) return;
+  if (r->d_table || r->d_pos || r->d_in || r->d_out) {
+    (void)hipSetDevice(r->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(r->d_table);
+    (void)hipFree(r->d_pos);
+    (void)hipFree(r->d_in);
+    (void)hipFree(r->d_out);
+  }
+  if (r->ev0) (void)hipEventDestroy(r->ev0);
+  if (r->ev1) (void)hipEventDestroy(r->ev1);
+  delete r;
+}
+
+int af_resampler_output_delay(const af_resampler *r) { return r ? r->plan.output_delay() : 0; }
+int64_t af_resampler_expected_frames(const af_resampler *r, int64_t n_in) { return r ? r->plan.expected_frames(n_in) : 0; }
+int af_resampler_sinc_len(const af_resampler *r) { return r ? r->plan.sinc_len : 0; }
+
+int af_resampler_copy_sinc_table(const af_resampler *r, double *out) {
+  if (!r || !out) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  const int stride = r->plan.row_stride();
+  for (int row = 0; row < af::kResampleOversampling; ++row)
+    std::memcpy(out + (size_t)row * r->plan.sinc_len, r->plan.table.data() + (size_t)row * stride + af::kResampleTablePad,
+                sizeof(double) * r->plan.sinc_len);
+  return AF_OK;
+}
+
+int af_resampler_plan(af_resampler *r, int64_t n_in, int64_t *n_out, int64_t *blocks) {
+  if (!r) return fail(AF_ERR_INVALID_ARGUMENT, "resampler is null");
+  if (n_in < 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_in must be >= 0");
+  if (int rc = resampler_plan(r, n_in)) return rc;
+  if (n_out) *n_out = r->planned_n_out;
+  if (blocks) *blocks = r->planned_blocks;
+  return AF_OK;
+}
+
+int af_resampler_process_device(af_resampler *r, const double *d_in, double *d_out, int64_t n_in, int32_t n_streams,
+                                int64_t in_stride, int64_t out_stride, void *stream) {
+  if (!r) return fail(AF_ERR_INVALID_ARGUMENT, "resampler is null");
+  if (n_streams <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_streams must be positive");
+  if (n_in < 0 || in_stride < n_in) return fail(AF_ERR_INVALID_ARGUMENT, "in_stride must cover n_in frames");
+  if (int rc = resampler_plan(r, n_in)) return rc;
+  if (out_stride < r->planned_n_out) return fail(AF_ERR_INVALID_ARGUMENT, "out_stride must cover the %lld planned output frames", (long long)r->planned_n_out);
+  if ((!d_in && n_in > 0) || !d_out) return fail(AF_ERR_INVALID_ARGUMENT, "null device buffer");
+  if (int rc = resampler_upload(r)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!r->ev0) {
+    AF_HIP(hipEventCreate(&r->ev0));
+    AF_HIP(hipEventCreate(&r->ev1));
+  }
+  AF_HIP(hipEventRecord(r->ev0, s));
+  AF_HIP(af::launch_resample(d_in, d_out, r->d_pos, r->d_table, n_in, r->planned_n_out, in_stride, out_stride, n_streams,
+                             r->plan.sinc_len, r->plan.ratio, s));
+  AF_HIP(hipEventRecord(r->ev1, s));
+  r->timed = true;
+  return AF_OK;
+}
+
+int af_resampler_process_host(af_resampler *r, const double *in, double *out, int64_t n_in, int32_t n_streams,
+                              int64_t in_stride, int64_t out_stride) {
+  if (!r) return fail(AF_ERR_INVALID_ARGUMENT, "resampler is null");
+  if (n_streams <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_streams must be positive");
+  if ((!in && n_in > 0) || !out) return fail(AF_ERR_INVALID_ARGUMENT, "null buffer");
+  if (n_in < 0 || in_stride < n_in) return fail(AF_ERR_INVALID_ARGUMENT, "in_stride must cover n_in frames");
+  for (int64_t s = 0; s < n_streams; ++s)
+    for (int64_t i = 0; i < n_in; ++i)
+      if (!std::isfinite(in[s * in_stride + i])) return fail(AF_ERR_NON_FINITE, "samples must be finite");
+  if (int rc = resampler_plan(r, n_in)) return rc;
+  const int64_t n_out = r->planned_n_out;
+  if (out_stride < n_out) return fail(AF_ERR_INVALID_ARGUMENT, "out_stride must cover the %lld planned output frames", (long long)n_out);
+  const int64_t need_in = std::max<int64_t>(1, (int64_t)n_streams * n_in), need_out = std::max<int64_t>(1, (int64_t)n_streams * n_out);
+  if (need_in > r->in_capacity) {
+    if (r->d_in) AF_HIP(hipFree(r->d_in));
+    r->d_in = nullptr;
+    AF_HIP(hipMalloc(&r->d_in, sizeof(double) * need_in));
+    r->in_capacity = need_in;
+  }
+  if (need_out > r->out_capacity) {
+    if (r->d_out) AF_HIP(hipFree(r->d_out));
+    r->d_out = nullptr;
+    AF_HIP(hipMalloc(&r->d_out, sizeof(double) * need_out));
+    r->out_capacity = need_out;
+  }
+  if (n_in > 0)
+    AF_HIP(hipMemcpy2D(r->d_in, sizeof(double) * n_in, in, sizeof(double) * in_stride, sizeof(double) * n_in, n_streams, hipMemcpyHostToDevice));
+  if (int rc = af_resampler_process_device(r, r->d_in, r->d_out, n_in, n_streams, n_in > 0 ? n_in : 1, n_out, nullptr)) return rc;
+  AF_HIP(hipStreamSynchronize(nullptr));
+  if (n_out > 0)
+    AF_HIP(hipMemcpy2D(out, sizeof(double) * out_stride, r->d_out, sizeof(double) * n_out, sizeof(double) * n_out, n_streams, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+int af_resampler_last_kernel_ms(af_resampler *r, double *ms) {
+  if (!r || !ms) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  *ms = 0.0;
+  if (!r->timed) return AF_OK;
+  AF_HIP(hipEventSynchronize(r->ev1));
+  float t = 0.0f;
+  AF_HIP(hipEventElapsedTime(&t, r->ev0, r->ev1));
+  *ms = t;
   return AF_OK;
 }
 

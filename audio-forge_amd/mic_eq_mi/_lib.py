@@ -127,6 +127,18 @@ SIGNATURES = {
     "af_engine_set_timing_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(_i32)]),
     "af_engine_last_stage_ms": (C.c_int, [_vp, _dp, _dp]),
+    # product resampler
+    "af_resampler_calculate_cutoff": (C.c_int, [_i32, _i32, C.POINTER(C.c_float)]),
+    "af_resampler_create": (C.c_int, [C.c_uint32, C.c_uint32, _i64, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "af_resampler_destroy": (None, [_vp]),
+    "af_resampler_output_delay": (C.c_int, [_vp]),
+    "af_resampler_expected_frames": (_i64, [_vp, _i64]),
+    "af_resampler_sinc_len": (C.c_int, [_vp]),
+    "af_resampler_copy_sinc_table": (C.c_int, [_vp, _dp]),
+    "af_resampler_plan": (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "af_resampler_process_device": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
+    "af_resampler_process_host": (C.c_int, [_vp, _dp, _dp, _i64, _i32, _i64, _i64]),
+    "af_resampler_last_kernel_ms": (C.c_int, [_vp, _dp]),
     "af_eq_magnitude_response": (C.c_int, [_dp, _sz, _dp, _d, _dp]),
     "af_eq_magnitude_response_v2": (C.c_int, [_dp, _sz, C.POINTER(EqBandConfig), _d, _dp]),
     "af_engine_eq_magnitude_response": (C.c_int, [_vp, _dp, _sz, _dp]),
@@ -136,6 +148,7 @@ SIGNATURES = {
 VALUE_FUNCTIONS = {
     "af_version", "af_last_error", "af_device_count", "af_engine_n_streams", "af_limiter_ceiling_db",
     "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy",
+    "af_resampler_destroy", "af_resampler_output_delay", "af_resampler_expected_frames", "af_resampler_sinc_len",
 }
 
 _lib = None

@@ -631,3 +631,123 @@ def eq_magnitude_response_v2(frequencies_hz: Sequence[float], bands, sample_rate
     _lib.check(_lib.load().af_eq_magnitude_response_v2(f.ctypes.data_as(dp), f.size, arr, float(sample_rate),
                                                         out.ctypes.data_as(dp)))
     return out.tolist()
+
+
+# ------------------------------------------------------------------ product resampler
+RESAMPLER_CHUNK_SIZE = 1024            # audio/processor.rs:53
+PRODUCT_RESAMPLER_SINC_LEN = 128       # audio/processor.rs:54
+PRODUCT_RESAMPLER_WINDOW_NAME = "blackman"  # audio/processor.rs:55
+RESAMPLER_WINDOW_IDS = {"blackman_harris": 0, "blackman_harris_squared": 1, "blackman": 2, "blackman_squared": 3,
+                        "hann": 4, "hann_squared": 5}  # resampler_window_from_name, resampling.rs:158-168
+
+
+def product_resampler_configuration() -> tuple[int, str, str, int, int]:
+    """resampling.rs:263-272."""
+    return (PRODUCT_RESAMPLER_SINC_LEN, PRODUCT_RESAMPLER_WINDOW_NAME, "cubic", 256, RESAMPLER_CHUNK_SIZE)
+
+
+class Resampler:
+    """One resampling plan (rates, chunk size, sinc length, window) for any number of equally long streams."""
+
+    def __init__(self, input_rate: int, output_rate: int, chunk_size: int = RESAMPLER_CHUNK_SIZE,
+                 sinc_len: int | None = None, window: str | None = None, device: int = 0):
+        # argument checks in the order of resampling.rs:187-214
+        if int(input_rate) <= 0 or int(output_rate) <= 0:
+            raise ValueError("sample rates must be positive")
+        if not 1 <= int(chunk_size) <= RESAMPLER_CHUNK_SIZE:
+            raise ValueError(f"chunk_size must be between 1 and {RESAMPLER_CHUNK_SIZE}")
+        sinc_len = PRODUCT_RESAMPLER_SINC_LEN if sinc_len is None else int(sinc_len)
+        if not 32 <= sinc_len <= 2048 or sinc_len & (sinc_len - 1):
+            raise ValueError("sinc_len must be a power of two between 32 and 2048")
+        name = PRODUCT_RESAMPLER_WINDOW_NAME if window is None else window
+        if name not in RESAMPLER_WINDOW_IDS:
+            raise ValueError(f"unsupported resampler window {name!r}")
+        self._lib = _lib.load()
+        handle = C.c_void_p()
+        _lib.check(self._lib.af_resampler_create(int(input_rate), int(output_rate), int(chunk_size), sinc_len,
+                                                 RESAMPLER_WINDOW_IDS[name], int(device), C.byref(handle)))
+        self._h = handle
+        self.input_rate, self.output_rate, self.sinc_len = int(input_rate), int(output_rate), sinc_len
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.af_resampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def output_delay(self) -> int:
+        return int(self._lib.af_resampler_output_delay(self._h))
+
+    def expected_frames(self, n_in: int) -> int:
+        return int(self._lib.af_resampler_expected_frames(self._h, int(n_in)))
+
+    def plan(self, n_in: int) -> tuple[int, int]:
+        """(frames the reference's driver loop returns for n_in input frames, number of chunks it runs)."""
+        n_out, blocks = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.af_resampler_plan(self._h, int(n_in), C.byref(n_out), C.byref(blocks)))
+        return n_out.value, blocks.value
+
+    def sinc_table(self) -> np.ndarray:
+        table = np.zeros((256, int(self._lib.af_resampler_sinc_len(self._h))), dtype=np.float64)
+        _lib.check(self._lib.af_resampler_copy_sinc_table(self._h, table.ctypes.data_as(C.POINTER(C.c_double))))
+        return table
+
+    def process(self, samples: np.ndarray) -> np.ndarray:
+        """[n_streams, n_in] (or [n_in]) float64 host array -> [n_streams, n_out]."""
+        x = np.ascontiguousarray(samples, dtype=np.float64)
+        squeeze = x.ndim == 1
+        if squeeze:
+            x = x.reshape(1, -1)
+        n_streams, n_in = x.shape
+        n_out, _ = self.plan(n_in)
+        out = np.zeros((n_streams, n_out), dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _lib.check(self._lib.af_resampler_process_host(self._h, x.ctypes.data_as(dp), out.ctypes.data_as(dp), n_in, n_streams,
+                                                       max(n_in, 1), max(n_out, 1) if n_out == 0 else n_out))
+        return out[0] if squeeze else out
+
+    def process_device(self, in_ptr: int, out_ptr: int, n_in: int, n_streams: int, in_stride: int, out_stride: int,
+                       hip_stream: int = 0) -> None:
+        _lib.check(self._lib.af_resampler_process_device(self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr), int(n_in),
+                                                         int(n_streams), int(in_stride), int(out_stride), C.c_void_p(hip_stream)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double(0.0)
+        _lib.check(self._lib.af_resampler_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+def simulate_product_resampler_batch(samples: np.ndarray, input_rate: int, output_rate: int,
+                                     chunk_size: int = RESAMPLER_CHUNK_SIZE, sinc_len: int | None = None,
+                                     window: str | None = None):
+    """Batched form: samples [n_streams, n] -> (output [n_streams, n_out] f64, delay, expected_frames, blocks)."""
+    r = Resampler(input_rate, output_rate, chunk_size, sinc_len, window)
+    try:
+        x = np.asarray(samples, dtype=np.float64)
+        if not np.all(np.isfinite(x)):
+            raise ValueError("samples must be finite")
+        out = r.process(x)
+        _, blocks = r.plan(x.shape[-1])
+        return out, r.output_delay, r.expected_frames(x.shape[-1]), blocks, r.last_kernel_ms()
+    finally:
+        r.close()
+
+
+def simulate_product_resampler(samples: Sequence[float], input_rate: int, output_rate: int,
+                               chunk_size: int = RESAMPLER_CHUNK_SIZE, sinc_len: int | None = None,
+                               window: str | None = None) -> tuple[list[float], int, int, list[int]]:
+    """resampling.rs:170-261: (output, delay, expected_frames, block_times_ns).
+
+    The reference times each 1024-frame chunk on the CPU; here all chunks run in one launch, so every entry
+    of block_times_ns is that launch's HIP-event time divided by the number of chunks."""
+    x = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1)
+    out, delay, expected, blocks, kernel_ms = simulate_product_resampler_batch(x.reshape(1, -1), input_rate, output_rate,
+                                                                             chunk_size, sinc_len, window)
+    per_block = int(round(kernel_ms * 1e6 / max(blocks, 1)))
+    return out[0].tolist(), int(delay), int(expected), [per_block] * int(blocks)

@@ -220,6 +220,43 @@ int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches);
 /* the same split at the suppressor | chain boundary (front-end pre-pass counts as suppressor time) */
 int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_ms);
 
+/* ---- product resampler ------------------------------------------------------------------
+ * `build_sinc_resampler_with_quality` + `simulate_product_resampler`
+ * (rust-core/src/audio/processor/resampling.rs:140-156, 179-261): rubato's asynchronous windowed-sinc
+ * resampler (sinc_len taps, 256 oversampled rows, cubic interpolation), driven in chunks of `chunk_size`
+ * frames: full chunks, one zero-padded partial chunk, then silent flush chunks until expected + delay
+ * frames exist.  One af_resampler serves any number of equally long f64 streams per call; audio is
+ * stream-major ([stream][frame], strides in frames).  Windows: resampler_window_from_name,
+ * resampling.rs:158-168. */
+typedef struct af_resampler af_resampler;
+enum { AF_WINDOW_BLACKMAN_HARRIS = 0, AF_WINDOW_BLACKMAN_HARRIS_SQUARED = 1, AF_WINDOW_BLACKMAN = 2,
+       AF_WINDOW_BLACKMAN_SQUARED = 3, AF_WINDOW_HANN = 4, AF_WINDOW_HANN_SQUARED = 5 };
+/* rubato::calculate_cutoff(sinc_len, window) (resampling.rs:149) */
+int af_resampler_calculate_cutoff(int32_t sinc_len, int32_t window, float *out);
+/* argument contract of resampling.rs:187-214 (AF_ERR_INVALID_ARGUMENT with the reference's messages);
+ * AF_ERR_UNSUPPORTED when sinc_len / ratio need a longer input span than the kernel's LDS tile */
+int af_resampler_create(uint32_t input_rate, uint32_t output_rate, int64_t chunk_size, int32_t sinc_len,
+                        int32_t window, int32_t device, af_resampler **out);
+void af_resampler_destroy(af_resampler *r);
+/* Resampler::output_delay (resampling.rs:216); VALUE, not a status */
+int af_resampler_output_delay(const af_resampler *r);
+/* round(n_in * output_rate / input_rate) (resampling.rs:217-218); VALUE */
+int64_t af_resampler_expected_frames(const af_resampler *r, int64_t n_in);
+/* effective sinc length (rounded up to a multiple of 8 like the crate); VALUE */
+int af_resampler_sinc_len(const af_resampler *r);
+/* the 256 x sinc_len coefficient table, row-major (diagnostics / cross-checks) */
+int af_resampler_copy_sinc_table(const af_resampler *r, double *out);
+/* host only: frames the reference's driver loop returns for n_in input frames, and how many chunks it runs */
+int af_resampler_plan(af_resampler *r, int64_t n_in, int64_t *n_out, int64_t *blocks);
+/* all streams, all chunks, one launch; writes af_resampler_plan's n_out frames per stream */
+int af_resampler_process_device(af_resampler *r, const double *d_in, double *d_out, int64_t n_in,
+                                int32_t n_streams, int64_t in_stride, int64_t out_stride, void *hip_stream);
+/* host buffers (checks "samples must be finite" -> AF_ERR_NON_FINITE) */
+int af_resampler_process_host(af_resampler *r, const double *in, double *out, int64_t n_in, int32_t n_streams,
+                              int64_t in_stride, int64_t out_stride);
+/* HIP-event time of the last launch */
+int af_resampler_last_kernel_ms(af_resampler *r, double *ms);
+
 /* ---- stateless helpers ----------------------------------------------------------- */
 /* eq_magnitude_response, lib.rs:99-150 (legacy (freq, gain_db, q) x 10 bands) */
 int af_eq_magnitude_response(const double *frequencies_hz, size_t n, const double bands[10][3],

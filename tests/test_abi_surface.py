@@ -164,3 +164,35 @@ def test_chain_diagnostics_host_logic_matches_oracle(oracle):
             assert value == ref, key
         else:
             assert abs(value - ref) <= 2e-5 * max(1.0, abs(ref)), (key, value, ref)
+
+
+def test_resampler_host_plan_matches_oracle(oracle):
+    """The resampler's host side (coefficient table, chunk-loop replay, argument contract) needs no GPU:
+    table bit-identical to the oracle's, frame/chunk counts identical for ragged lengths and ratios."""
+    import ctypes as C
+
+    from mic_eq_mi import mic_eq_core as core
+
+    L = oracle.lib()
+    L.afo_resampler_new.restype = C.c_void_p
+    L.afo_resampler_new.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, C.c_int, C.c_float]
+    L.afo_resampler_sinc_table.restype = C.POINTER(C.c_double)
+    L.afo_resampler_sinc_table.argtypes = [C.c_void_p]
+    L.afo_resampler_free.argtypes = [C.c_void_p]
+    for fi, fo, sinc_len, window in ((44_100, 48_000, 128, "blackman"), (48_000, 44_100, 128, "blackman"),
+                                     (48_000, 44_100, 256, "blackman_harris_squared"), (32_000, 48_000, 64, "hann_squared")):
+        r = core.Resampler(fi, fo, 1024, sinc_len, window)
+        h = L.afo_resampler_new(fi, fo, 1024, sinc_len, oracle.RESAMPLER_WINDOWS[window], 0.0)
+        table = np.ctypeslib.as_array(L.afo_resampler_sinc_table(h), shape=(256, sinc_len))
+        assert np.array_equal(r.sinc_table(), table)
+        L.afo_resampler_free(h)
+        for n in (0, 1, 1023, 1024, 1025, 44_100, 100_003):
+            y, delay, expected, blocks = oracle.simulate_product_resampler(np.zeros(n), fi, fo, 1024, sinc_len, window)
+            assert r.plan(n) == (y.size, blocks), (fi, fo, n)
+            assert (r.output_delay, r.expected_frames(n)) == (delay, expected)
+        r.close()
+    assert core.product_resampler_configuration() == (128, "blackman", "cubic", 256, 1024)  # tests.rs:209-221
+    for bad in ((0, 48_000, 1024, None, None), (48_000, 44_100, 0, None, None), (48_000, 44_100, 1025, None, None),
+                (48_000, 44_100, 1024, 96, None), (48_000, 44_100, 1024, 4096, None), (48_000, 44_100, 1024, None, "unknown")):
+        with pytest.raises(ValueError):
+            core.Resampler(*bad)
