@@ -101,6 +101,7 @@ struct af_engine {
   hipStream_t last_stream = nullptr;
   af::SuppressorHost supp;
   hipStream_t aux_stream = nullptr;                      // chain launches while the suppressor fills the chip
+  hipStream_t pre_stream = nullptr;                      // the suppressor's sample-serial pre-pass, one window ahead
   std::vector<hipEvent_t> sync_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
   int supp_window_frames = 50;
@@ -469,6 +470,7 @@ void af_engine_destroy(af_engine *e) {
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
+  if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
   if (e->supp.d_blob || e->supp.d_state || e->supp.d_xh) {
     (void)hipSetDevice(e->device);
     e->supp.release_all();
@@ -715,9 +717,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
 
   // ---- RNNoise suppressor ahead of the chain (realtime order, dsp_loop.rs:1222-1250,1521-1599).
-  // The call is cut into windows of frames.  Window w's suppressor kernels (which fill the whole chip) run
-  // on the caller's stream; the chain launch over the same window (64 streams per workgroup, a quarter of
-  // the CUs at batch 4096) runs on a second stream behind an event, so it overlaps window w+1's suppressor.
+  // The call is cut into windows of frames and runs as a three-stage pipeline over them:
+  //   pre stream    : window w+1's sample-serial pre-pass (front end + model-input high-pass; 64 waves whose
+  //                   duration is set by recurrence latency, so it costs the chip almost nothing)
+  //   caller stream : window w's frame-parallel suppressor kernels (these fill the chip)
+  //   chain stream  : window w-1's chain launch (64 streams per workgroup, a quarter of the CUs at batch 4096)
+  // ordered by events; the two model-input buffers alternate between consecutive windows.
   if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
   if (n_samples % af::kRnnFrame != 0)
     return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
@@ -743,6 +748,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   window = std::min<int64_t>(window, frames);
   AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+  if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   int64_t blocks_done = 0;
   size_t ev_index = 0;
   auto next_event = [&](hipEvent_t *out_ev) -> int {
@@ -754,18 +760,18 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     *out_ev = e->sync_events[ev_index++];
     return AF_OK;
   };
-  {  // the chain stream starts after whatever the caller queued before this call
+  {  // the side streams start after whatever the caller queued before this call
     hipEvent_t ev;
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, stream));
     AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
+    AF_HIP(hipStreamWaitEvent(e->pre_stream, ev, 0));
   }
-  for (int64_t f0 = 0; f0 < frames; f0 += window) {
-    const int64_t nf = std::min<int64_t>(window, frames - f0);
+  auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
     af::SuppArgs sa{};
     sa.in = in;
     sa.out = out;
-    sa.xh = e->supp.d_xh;
+    sa.xh = e->supp.d_xh + (size_t)(index & 1) * e->supp.xh_floats;
     sa.X = e->supp.d_X;
     sa.P = e->supp.d_P;
     sa.rec = e->supp.d_rec;
@@ -786,13 +792,30 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     sa.chain_st32 = e->d_st32;
     sa.f64_pre_z1 = af::kPreZ1;
     sa.f32_dc_x1 = af::kDcX1;
-    if (f0 > 0) {  // the workspace is reused: this window's kernels follow the previous window's on `stream` anyway
+    if (index > 0) {  // history = tail of the previous window's buffer (all earlier windows are `window` frames long)
+      sa.xh_prev = e->supp.d_xh + (size_t)((index - 1) & 1) * e->supp.xh_floats;
+      sa.xh_prev_stride = af::kPitchBuf + window * af::kRnnFrame;
     }
+    return sa;
+  };
+  std::vector<hipEvent_t> window_done;  // window w's frame-parallel kernels finished (its model-input buffer is free)
+  int64_t index = 0;
+  for (int64_t f0 = 0; f0 < frames; f0 += window, ++index) {
+    const int64_t nf = std::min<int64_t>(window, frames - f0);
+    const af::SuppArgs sa = window_args(f0, nf, index);
+    // pre-pass of this window, possibly while the previous window's kernels still run
+    if (index >= 2) AF_HIP(hipStreamWaitEvent(e->pre_stream, window_done[index - 2], 0));
+    AF_HIP(af::launch_suppressor_prefilter(sa, e->pre_stream));
+    hipEvent_t ev_pre;
+    if (int rc = next_event(&ev_pre)) return rc;
+    AF_HIP(hipEventRecord(ev_pre, e->pre_stream));
+    AF_HIP(hipStreamWaitEvent(stream, ev_pre, 0));
     AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
     e->last_launches += 7;
     hipEvent_t ev;
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, stream));
+    window_done.push_back(ev);
     AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
     const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;

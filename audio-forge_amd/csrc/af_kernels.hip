@@ -471,12 +471,14 @@ extern "C" __global__ __launch_bounds__(kLanes) void chain_lane_kernel(LaunchArg
     if (flags & kFlagLimiter) {
       for (int r = 0; r < 2 * W; ++r) a.st32[(int64_t)(kLimRing + r) * NS + s] = lim_lds[(size_t)r * kLanes + lane];
     }
-    a.st32[(int64_t)kDcX1 * NS + s] = dc_x1;
-    a.st32[(int64_t)kDcY1 * NS + s] = dc_y1;
+    if (flags & kFlagDcBlock) {  // otherwise the front-end rows belong to whoever runs the front end
+      a.st32[(int64_t)kDcX1 * NS + s] = dc_x1;
+      a.st32[(int64_t)kDcY1 * NS + s] = dc_y1;
+      a.st64[(int64_t)kPreZ1 * NS + s] = pre_z1;
+      a.st64[(int64_t)kPreZ2 * NS + s] = pre_z2;
+    }
     a.st32[(int64_t)kTpGain * NS + s] = tp_gain;
     a.st32[(int64_t)kLimPrefix * NS + s] = lim_prefix;
-    a.st64[(int64_t)kPreZ1 * NS + s] = pre_z1;
-    a.st64[(int64_t)kPreZ2 * NS + s] = pre_z2;
     a.st64[(int64_t)kLimGain * NS + s] = lim_gain;
     a.st64[(int64_t)kCompScPrevIn * NS + s] = cs.sc_prev_in;
     a.st64[(int64_t)kCompScPrevOut * NS + s] = cs.sc_prev_out;

@@ -819,7 +819,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
       a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + s] = L64(row);
     }
-    if (wave == 0) {
+    if (wave == 0 && (flags & kFlagDcBlock)) {
       a.st64[(int64_t)kPreZ1 * NS + s] = L64(kR64PreZ1);
       a.st64[(int64_t)kPreZ2 * NS + s] = L64(kR64PreZ2);
       a.st32[(int64_t)kDcX1 * NS + s] = L32(kR32DcX1);
@@ -827,7 +827,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
     }
   } else if (valid) {
     struct Map { int row, field; };
-    const Map m64[] = {{kR64PreZ1, kPreZ1}, {kR64PreZ2, kPreZ2}, {kR64ScPrevIn, kCompScPrevIn},
+    // the front-end rows (DC block, 80 Hz high-pass) are written back only by the launch that runs the front end:
+    // with the suppressor on they belong to supp_prefilter_kernel, which may already be working on the next window
+    const Map m64[] = {{kR64ScPrevIn, kCompScPrevIn},
                        {kR64ScPrevOut, kCompScPrevOut}, {kR64LowEnv, kCompLowEnv}, {kR64VoicedEnv, kCompVoicedEnv},
                        {kR64PresenceEnv, kCompPresenceEnv}, {kR64Plosive, kCompPlosive}, {kR64PeakEnvDb, kCompPeakEnvDb},
                        {kR64RmsEnvSq, kCompRmsEnvSq}, {kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv},
@@ -854,8 +856,12 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       a.st64[(int64_t)kCompReleaseCoeff * NS + s] =
           P.comp.adaptive_release ? exp(-1.0 / (tau * P.comp.sample_rate)) : L64(kR64ReleaseCoeff);
       if (!(flags & kFlagCompressor)) a.st64[(int64_t)kCompGr * NS + s] = 0.0;
-      a.st32[(int64_t)kDcX1 * NS + s] = L32(kR32DcX1);
-      a.st32[(int64_t)kDcY1 * NS + s] = L32(kR32DcY1);
+      if (flags & kFlagDcBlock) {
+        a.st32[(int64_t)kDcX1 * NS + s] = L32(kR32DcX1);
+        a.st32[(int64_t)kDcY1 * NS + s] = L32(kR32DcY1);
+        a.st64[(int64_t)kPreZ1 * NS + s] = L64(kR64PreZ1);
+        a.st64[(int64_t)kPreZ2 * NS + s] = L64(kR64PreZ2);
+      }
       a.st32[(int64_t)kTpGain * NS + s] = L32(kR32TpGain);
       a.st32[(int64_t)kLimPrefix * NS + s] = L32(kR32LimPrefix);
     }

@@ -61,90 +61,119 @@ __device__ __forceinline__ float scale_for_model(float sample) {
   return scaled < -kLimit ? -kLimit : (scaled > kLimit ? kLimit : scaled);
 }
 
-// The pass is bound by memory latency (one row load per stream per tile), not by arithmetic, so a wave
-// owns only kPreGroup streams: more waves in flight, fewer dependent loads per wave.
-constexpr int kPreGroup = 8;
-extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
+// The pass is a chain of short per-sample recurrences (DC block, 80 Hz high-pass in f64, the model's own
+// high-pass), so its duration is samples x recurrence latency whatever the lane count: one wave takes 64
+// streams (lane = stream), keeps a whole 64-sample tile of its stream in registers so that no LDS or HBM
+// latency sits inside the recurrence, and has the next tile's 64 row loads in flight while it computes.
+constexpr int kPreGroup = 64;
+constexpr int kPreChunk = 16;  // samples held in registers at a time
+template <bool kClamp, bool kDcHp, bool kRaw>
+__global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
   __shared__ float tile[64][kPreGroup + 1];
   __shared__ float dry[64][kPreGroup + 1];
+  constexpr bool kFront = kClamp || kDcHp;
   const int lane = threadIdx.x;
   const int s0 = blockIdx.x * kPreGroup;
   const int s = s0 + lane;
-  const bool valid = lane < kPreGroup && s < a.n_streams;
+  const bool valid = s < a.n_streams;
   const int sc = valid ? s : a.n_streams - 1;
   const int64_t NS = a.n_streams;
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
   const int64_t xh_stride = kPitchBuf + n;
-  const bool front = a.front_clamp || a.front_dc;
   float *st = a.state + (int64_t)sc * SuppState::kCount;
   float m0 = st[SuppState::kHpMem], m1 = st[SuppState::kHpMem + 1];
   // realtime front end state (chain planes): DC block x1/y1 (f32), 80 Hz high-pass z1/z2 (f64)
   float dc_x1 = 0.0f, dc_y1 = 0.0f;
   double z1 = 0.0, z2 = 0.0;
-  if (a.front_dc) {
+  if (kDcHp) {
     dc_x1 = a.chain_st32[(int64_t)a.f32_dc_x1 * NS + sc];
     dc_y1 = a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + sc];
     z1 = a.chain_st64[(int64_t)a.f64_pre_z1 * NS + sc];
     z2 = a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + sc];
   }
-  // history: the previous 1728 model-input samples go in front of the window
-  for (int r = 0; r < kPreGroup; ++r) {
-    const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
-#pragma unroll 9
-    for (int i = lane; i < kPitchBuf; i += 64)
-      a.xh[(int64_t)sr * xh_stride + i] = a.state[(int64_t)sr * SuppState::kCount + SuppState::kHist + i];
-  }
-  const float b0 = -2.0f, b1 = 1.0f, a0 = -1.99599f, a1 = 0.99600f;  // RNNoise input high-pass
-  for (int64_t t0 = 0; t0 < n; t0 += 64) {
-    // n is a multiple of 480, so every tile except possibly the last is full; rows are clamped, not skipped,
-    // so the 64 row loads of a tile are independent and stay in flight together
+  const int64_t ntiles = (n + 63) / 64;
+  float nxt[kPreGroup];
+  // rows are clamped, not skipped, so the 64 row loads of a tile are independent and stay in flight together
+  auto fetch = [&](int64_t t0) {
     const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
     const int64_t col = a.frame0 * kRnnFrame + t0 + (lane < len ? lane : len - 1);
 #pragma unroll
     for (int r = 0; r < kPreGroup; ++r) {
       const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
-      tile[lane][r] = a.in[(int64_t)sr * a.stream_stride + col];
+      nxt[r] = a.in[(int64_t)sr * a.stream_stride + col];
     }
-    __syncthreads();
-    if (lane < kPreGroup)
-    for (int t = 0; t < len; ++t) {
-      float x = tile[t][lane];
-      if (front) {
-        if (!finite32(x)) x = 0.0f;                                              // routing.rs:808-811
-        if (a.front_clamp) x = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);        // routing.rs:822
-        if (a.front_dc) {                                                        // routing.rs:832-840
-          const float o = x - dc_x1 + 0.995f * dc_y1;
-          dc_x1 = x;
-          dc_y1 = o;
-          x = o;
-          if (a.front_hp) {
-            const double xin = (double)o;
-            const double y = a.hp_b0 * xin + z1;
-            z1 = a.hp_b1 * xin - a.hp_a1 * y + z2;
-            z2 = a.hp_b2 * xin - a.hp_a2 * y;
-            x = (float)y;
-          }
-        }
-        dry[t][lane] = x;
-      }
-      if (a.raw_protocol) {  // bin/rnnoise_benchmark.rs:75-79
-        x = (x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x)) * 32768.0f;
-      } else {
-        x = scale_for_model(x);
-      }
-      const float y = x + m0;
-      m0 = m1 + (b0 * x - a0 * y);
-      m1 = (b1 * x - a1 * y);
-      tile[t][lane] = y;
-    }
-    __syncthreads();
+  };
+  if (ntiles > 0) fetch(0);
+  // history: the previous 1728 model-input samples go in front of the window -- the tail of the previous
+  // window's buffer when there is one (its kernels may still be running), else what the last call saved
+  for (int r = 0; r < kPreGroup; ++r) {
+    const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
+    const float *hist = a.xh_prev ? a.xh_prev + (int64_t)sr * a.xh_prev_stride + (a.xh_prev_stride - kPitchBuf)
+                                  : a.state + (int64_t)sr * SuppState::kCount + SuppState::kHist;
+#pragma unroll 9
+    for (int i = lane; i < kPitchBuf; i += 64) a.xh[(int64_t)sr * xh_stride + i] = hist[i];
+  }
+  const float b0 = -2.0f, b1 = 1.0f, a0 = -1.99599f, a1 = 0.99600f;  // RNNoise input high-pass
+  const double hb0 = a.hp_b0, hb1 = a.hp_b1, hb2 = a.hp_b2, ha1 = a.hp_a1, ha2 = a.hp_a2;
+  const bool hp_on = a.front_hp != 0;
+  for (int64_t ti = 0; ti < ntiles; ++ti) {
+    const int64_t t0 = ti * 64;
+    const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
 #pragma unroll
+    for (int r = 0; r < kPreGroup; ++r) tile[lane][r] = nxt[r];
+    __syncthreads();
+    if (ti + 1 < ntiles) fetch(t0 + 64);
+    for (int c0 = 0; c0 < len; c0 += kPreChunk) {
+      float x[kPreChunk], d[kPreChunk];
+#pragma unroll
+      for (int t = 0; t < kPreChunk; ++t) x[t] = tile[c0 + t][lane];
+#pragma unroll
+      for (int t = 0; t < kPreChunk; ++t) {
+        if (c0 + t < len) {
+          float v = x[t];
+          if (kFront) {
+            if (!finite32(v)) v = 0.0f;                                        // routing.rs:808-811
+            if (kClamp) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);        // routing.rs:822
+            if (kDcHp) {                                                       // routing.rs:832-840
+              const float o = v - dc_x1 + 0.995f * dc_y1;
+              dc_x1 = v;
+              dc_y1 = o;
+              v = o;
+              if (hp_on) {
+                const double xin = (double)o;
+                const double y = hb0 * xin + z1;
+                z1 = hb1 * xin - ha1 * y + z2;
+                z2 = hb2 * xin - ha2 * y;
+                v = (float)y;
+              }
+            }
+            d[t] = v;
+          }
+          if (kRaw) {  // bin/rnnoise_benchmark.rs:75-79
+            v = (v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v)) * 32768.0f;
+          } else {
+            v = scale_for_model(v);
+          }
+          const float y = v + m0;
+          m0 = m1 + (b0 * v - a0 * y);
+          m1 = (b1 * v - a1 * y);
+          x[t] = y;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < kPreChunk; ++t) {
+        tile[c0 + t][lane] = x[t];  // own column: nobody else reads it before the barrier
+        if (kFront) dry[c0 + t][lane] = d[t];
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
     for (int r = 0; r < kPreGroup; ++r) {
       const int sr = s0 + r;
       if (sr < a.n_streams && lane < len) {
         a.xh[(int64_t)sr * xh_stride + kPitchBuf + t0 + lane] = tile[lane][r];
         // the dry signal the wet/dry mix sees is the suppressor's input, i.e. the front end's output
-        if (front) a.out[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + t0 + lane] = dry[lane][r];
+        if (kFront) a.out[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + t0 + lane] = dry[lane][r];
       }
     }
     __syncthreads();
@@ -152,7 +181,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs 
   if (valid) {
     st[SuppState::kHpMem] = m0;
     st[SuppState::kHpMem + 1] = m1;
-    if (a.front_dc) {
+    if (kDcHp) {
       a.chain_st32[(int64_t)a.f32_dc_x1 * NS + s] = dc_x1;
       a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + s] = dc_y1;
       a.chain_st64[(int64_t)a.f64_pre_z1 * NS + s] = z1;
@@ -1092,13 +1121,31 @@ extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a)
 }
 
 // ============================================================================== launch
+// The sample-serial pre-pass of a window (independent of the other kernels: it may run a window ahead).
+hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
+  const dim3 grid((a.n_streams + kPreGroup - 1) / kPreGroup), block(64);
+  const int sel = (a.front_clamp ? 4 : 0) | (a.front_dc ? 2 : 0) | (a.raw_protocol ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((supp_prefilter_kernel<false, false, false>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((supp_prefilter_kernel<false, false, true>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((supp_prefilter_kernel<false, true, false>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((supp_prefilter_kernel<false, true, true>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((supp_prefilter_kernel<true, false, false>), grid, block, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL((supp_prefilter_kernel<true, false, true>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((supp_prefilter_kernel<true, true, false>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((supp_prefilter_kernel<true, true, true>), grid, block, 0, stream, a); break;
+  }
+  return hipGetLastError();
+}
+
+// Everything downstream of the pre-pass for one window.
 hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
-  hipLaunchKernelGGL(supp_prefilter_kernel, dim3((a.n_streams + kPreGroup - 1) / kPreGroup), dim3(64), 0, stream, a);
-  hipLaunchKernelGGL(supp_spectrum_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
+  const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
+  hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
-  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
-  hipLaunchKernelGGL(supp_resynth_kernel, dim3((unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave))), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

@@ -76,6 +76,8 @@ struct SuppArgs {
   const float *in;            // chain input, [stream][stride]
   float *out;                 // suppressor output, same layout
   float *xh;                  // [stream][1728 + n_frames*480] scaled + high-passed model input
+  const float *xh_prev;       // the previous window's buffer (history source for the pre-pass), or null: use `state`
+  int64_t xh_prev_stride;     // 1728 + its frame count * 480
   float2 *X, *P;              // [frame][stream][481]
   SuppFrameRec *rec;          // [frame][stream]
   float *state;               // [stream][SuppState::kCount]

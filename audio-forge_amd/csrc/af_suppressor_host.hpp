@@ -12,6 +12,7 @@
 namespace af {
 
 hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream);
+hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
 
 // int8 network weights in the layout of the public RNNoise model (dense: [in][out]; GRU: [in][3*units],
 // gate order z | r | h).  The trained weights of nnnoiseless 0.5.2 are embedded in that crate and are not
@@ -74,6 +75,7 @@ struct SuppressorHost {
   SuppTables tables{};
   float *d_state = nullptr;  // [streams][SuppState::kCount]
   float *d_xh = nullptr;
+  size_t xh_floats = 0;  // floats per model-input buffer (there are two)
   float2 *d_X = nullptr, *d_P = nullptr;
   SuppFrameRec *d_rec = nullptr;
   int ws_frames = 0, ws_streams = 0;
@@ -199,7 +201,9 @@ struct SuppressorHost {
     release_workspace();
     hipError_t err;
     const size_t cells = (size_t)frames * n_streams;
-    if ((err = hipMalloc(&d_xh, sizeof(float) * (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame))) != hipSuccess) return err;
+    // two model-input buffers: the pre-pass of window w+1 fills one while window w's kernels read the other
+    if ((err = hipMalloc(&d_xh, sizeof(float) * 2 * (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame))) != hipSuccess) return err;
+    xh_floats = (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame);
     if ((err = hipMalloc(&d_X, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_P, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * cells)) != hipSuccess) return err;
