@@ -191,76 +191,127 @@ __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
 }
 
 // ============================================================================== FFT-960 on one wave
-// 960 = 15 x 64.  Lane n2 does the 15-point DFTs over n1 (x[64 n1 + n2]) in registers, twiddles, then
-// the fifteen 64-point transforms across lanes run as two radix-8 passes through LDS.
-// out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.  `a` is consumed; the result lands in `b`.
+// 960 = 15 x 64.  Lane n2 transforms x[64 n1 + n2] over n1 in registers as a 3 x 5 prime-factor DFT (no
+// twiddles between the two), applies W_960^(n2 k1), and the fifteen 64-point transforms across lanes run as
+// two passes of radix-8 butterflies through LDS (120 butterflies per pass, two per lane).
+// out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.  `a` is consumed (and reused as scratch, so it must
+// hold kFftBuf elements); the result lands in `b`.
+constexpr int kFftBuf = 15 * 72;  // fifteen 8 x 8 tiles with 9-element rows: conflict-free in both passes
+
 __device__ __forceinline__ float2 cmul(float2 x, float2 w) { return make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x); }
+__device__ __forceinline__ float2 cadd(float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); }
+__device__ __forceinline__ float2 csub(float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); }
+__device__ __forceinline__ float2 mulmj(float2 z) { return make_float2(z.y, -z.x); }  // z * (-i)
 
 // Per-lane twiddles are loop invariants of the whole kernel: W_960^(lane*k1) for the fifteen k1 and
-// W_64^(q*r) of the lane's radix-8 cell live in registers; W_15 and W_8 are literals.
+// W_64^(q r) of the lane's radix-8 cell live in registers.
 struct FftLane {
   float2 tw960[15];
-  float2 tw64;
+  float2 tw64[8];
 };
 __device__ __forceinline__ FftLane fft_lane_init(const float2 *tw, int lane) {
   FftLane f;
 #pragma unroll
-  for (int k1 = 0; k1 < 15; ++k1) f.tw960[k1] = tw[(lane * k1) % kRnnWindow];
-  f.tw64 = tw[(lane & 7) * (lane >> 3) * 15];
+  for (int k1 = 0; k1 < 15; ++k1) f.tw960[k1] = tw[lane * k1];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) f.tw64[r] = tw[15 * (lane & 7) * r];
   return f;
 }
 
+__device__ __forceinline__ void dft3(float2 x0, float2 x1, float2 x2, float2 &y0, float2 &y1, float2 &y2) {
+  const float c = 0.86602540378443864676f;  // sin(pi/3)
+  const float2 t = cadd(x1, x2), d = csub(x1, x2);
+  y0 = cadd(x0, t);
+  const float2 m = make_float2(x0.x - 0.5f * t.x, x0.y - 0.5f * t.y);
+  const float2 sj = make_float2(d.y * c, -d.x * c);
+  y1 = cadd(m, sj);
+  y2 = csub(m, sj);
+}
+__device__ __forceinline__ void dft5(const float2 *x, float2 *y) {
+  const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+  const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+  const float2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), d1 = csub(x[1], x[4]), d2 = csub(x[2], x[3]);
+  y[0] = make_float2(x[0].x + t1.x + t2.x, x[0].y + t1.y + t2.y);
+  const float2 m1 = make_float2(x[0].x + c1 * t1.x + c2 * t2.x, x[0].y + c1 * t1.y + c2 * t2.y);
+  const float2 m2 = make_float2(x[0].x + c2 * t1.x + c1 * t2.x, x[0].y + c2 * t1.y + c1 * t2.y);
+  const float2 n1 = mulmj(make_float2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y));
+  const float2 n2 = mulmj(make_float2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y));
+  y[1] = cadd(m1, n1);
+  y[4] = csub(m1, n1);
+  y[2] = cadd(m2, n2);
+  y[3] = csub(m2, n2);
+}
+// 8-point DFT, radix-2 decimation in time
+__device__ __forceinline__ void dft8(const float2 *v, float2 *V) {
+  const float h = 0.70710678118654752440f;
+  const float2 a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]), a2 = cadd(v[2], v[6]), a3 = mulmj(csub(v[2], v[6]));
+  const float2 a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]), a6 = cadd(v[3], v[7]), a7 = mulmj(csub(v[3], v[7]));
+  const float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
+  const float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = csub(a5, a7);
+  const float2 w1 = make_float2((b5.x + b5.y) * h, (b5.y - b5.x) * h);   // b5 * W8^1
+  const float2 w2 = mulmj(b6);                                           // b6 * W8^2
+  const float2 w3 = make_float2((b7.y - b7.x) * h, -(b7.x + b7.y) * h);  // b7 * W8^3
+  V[0] = cadd(b0, b4);
+  V[4] = csub(b0, b4);
+  V[1] = cadd(b1, w1);
+  V[5] = csub(b1, w1);
+  V[2] = cadd(b2, w2);
+  V[6] = csub(b2, w2);
+  V[3] = cadd(b3, w3);
+  V[7] = csub(b3, w3);
+}
+
 __device__ __forceinline__ void fft960_wave(float2 *a, float2 *b, const FftLane &fl, int lane, float scale) {
-  float2 xin[15];
+  float2 x[15];
 #pragma unroll
-  for (int n1 = 0; n1 < 15; ++n1) xin[n1] = a[64 * n1 + lane];
-  __syncthreads();
-#pragma unroll
-  for (int k1 = 0; k1 < 15; ++k1) {
-    float2 acc = make_float2(0.0f, 0.0f);
-#pragma unroll
-    for (int n1 = 0; n1 < 15; ++n1) {
-      const float2 w = make_float2(kW15[(n1 * k1) % 15][0], kW15[(n1 * k1) % 15][1]);
-      const float2 p = cmul(xin[n1], w);
-      acc.x += p.x;
-      acc.y += p.y;
-    }
-    b[k1 * 64 + lane] = cmul(acc, fl.tw960[k1]);
-  }
+  for (int n1 = 0; n1 < 15; ++n1) x[n1] = a[64 * n1 + lane];
   __syncthreads();
   {
-    const int q = lane & 7, r = lane >> 3;
-    float2 w8[8];
+    // n1 = (5 na + 3 nb) mod 15, k1 = (10 ka + 6 kb) mod 15: a plain 3 x 5 two-dimensional DFT
+    float2 t[3][5];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) w8[p] = make_float2(kW8[(p * r) & 7][0], kW8[(p * r) & 7][1]);
-#pragma unroll 3
-    for (int k1 = 0; k1 < 15; ++k1) {
-      float2 acc = make_float2(0.0f, 0.0f);
+    for (int nb = 0; nb < 5; ++nb)
+      dft3(x[(3 * nb) % 15], x[(5 + 3 * nb) % 15], x[(10 + 3 * nb) % 15], t[0][nb], t[1][nb], t[2][nb]);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const float2 v = cmul(b[k1 * 64 + 8 * p + q], w8[p]);
-        acc.x += v.x;
-        acc.y += v.y;
+    for (int ka = 0; ka < 3; ++ka) {
+      float2 y[5];
+      dft5(t[ka], y);
+#pragma unroll
+      for (int kb = 0; kb < 5; ++kb) {
+        const int k1 = (10 * ka + 6 * kb) % 15;
+        b[k1 * 64 + lane] = cmul(y[kb], fl.tw960[k1]);
       }
-      a[k1 * 64 + q * 8 + r] = cmul(acc, fl.tw64);
     }
   }
   __syncthreads();
-  {
-    const int r = lane & 7, t = lane >> 3;
-    float2 w8[8];
+  // 64 = 8 x 8, n2 = 8 p + q, k2 = r + 8 t.  Pass A: cell (k1, q): 8-point DFT over p, times W_64^(q r).
 #pragma unroll
-    for (int q = 0; q < 8; ++q) w8[q] = make_float2(kW8[(q * t) & 7][0], kW8[(q * t) & 7][1]);
-#pragma unroll 3
-    for (int k1 = 0; k1 < 15; ++k1) {
-      float2 acc = make_float2(0.0f, 0.0f);
+  for (int half = 0; half < 2; ++half) {
+    const int id = lane + 64 * half;
+    if (id < 120) {
+      const int k1 = id >> 3, q = id & 7;
+      float2 v[8], V[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float2 v = cmul(a[k1 * 64 + q * 8 + r], w8[q]);
-        acc.x += v.x;
-        acc.y += v.y;
-      }
-      b[k1 + 15 * (r + 8 * t)] = make_float2(acc.x * scale, acc.y * scale);
+      for (int pp = 0; pp < 8; ++pp) v[pp] = b[k1 * 64 + 8 * pp + q];
+      dft8(v, V);
+      a[k1 * 72 + q] = V[0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) a[k1 * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
+    }
+  }
+  __syncthreads();
+  // Pass B: cell (k1, r): 8-point DFT over q; output bin k1 + 15 (r + 8 t).
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int id = lane + 64 * half;
+    if (id < 120) {
+      const int k1 = id >> 3, r = id & 7;
+      float2 v[8], V[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = a[k1 * 72 + r * 9 + q];
+      dft8(v, V);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[k1 + 15 * (r + 8 * t)] = make_float2(V[t].x * scale, V[t].y * scale);
     }
   }
   __syncthreads();
@@ -286,35 +337,52 @@ __device__ __forceinline__ float wave_dot64_sq_stride2(const float *y, int n, in
 }
 
 // compute_band_energy / compute_band_corr: band b = R_b + F_b, the rising ramp over band b-1's bins and the
-// falling ramp over band b's bins, each summed left to right on its own lane (lane 2b, lane 2b+1).
+// falling ramp over band b's bins.  Evaluation order (shared with the CPU restatement): every band segment is
+// cut into blocks of 8 bins (54 blocks in all, one lane each), a block is summed left to right, and a
+// segment's block sums are added in block order -- a dependent chain of 8 + 11 additions instead of 88.
 // `frac` holds (float)j / (float)band_size per bin, evaluated once on the host (the same IEEE division).
-// Lanes 0..21 return band `lane`.
-__device__ __forceinline__ float band_accumulate_wave(const float2 *X, const float2 *Pm, const float *frac, int lane) {
-  const int b = lane >> 1;
-  const bool falling = lane & 1;
-  float sum = 0.0f;
-  if (lane < 2 * kRnnBands) {
-    if (!falling && b > 0) {
-      const int e0 = c_eband[b - 1] << 2, size = (c_eband[b] - c_eband[b - 1]) << 2;
-#pragma unroll 4
-      for (int j = 0; j < size; ++j) {
+// `scratch` is 128 floats of LDS.  Lanes 0..21 return band `lane`.
+__constant__ uint16_t c_blk_first[54] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224, 232, 240, 248, 256, 264, 272, 280, 288, 296, 304, 312, 320, 328, 336, 344, 352, 360, 368, 376, 384, 392};
+__constant__ uint8_t c_blk_count[54] = {4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+__constant__ uint8_t c_seg_blk0[21] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21, 24, 28, 34, 43};
+__constant__ uint8_t c_seg_nblk[21] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 6, 9, 11};
+constexpr int kBandBlocks = 54;
+
+__device__ __forceinline__ float band_accumulate_wave(const float2 *X, const float2 *Pm, const float *frac, int lane,
+                                                      float *scratch) {
+  float rise = 0.0f, fall = 0.0f;
+  if (lane < kBandBlocks) {
+    const int e0 = c_blk_first[lane], count = c_blk_count[lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < count) {
         const float2 x = X[e0 + j], p = Pm[e0 + j];
-        sum += frac[e0 + j] * (x.x * p.x + x.y * p.y);
-      }
-    }
-    if (falling && b < kRnnBands - 1) {
-      const int e0 = c_eband[b] << 2, size = (c_eband[b + 1] - c_eband[b]) << 2;
-#pragma unroll 4
-      for (int j = 0; j < size; ++j) {
-        const float2 x = X[e0 + j], p = Pm[e0 + j];
-        sum += (1 - frac[e0 + j]) * (x.x * p.x + x.y * p.y);
+        const float fr = frac[e0 + j];
+        const float tmp = x.x * p.x + x.y * p.y;
+        fall += (1 - fr) * tmp;
+        rise += fr * tmp;
       }
     }
   }
-  const float other = __shfl_down(sum, 1);  // lane 2b: rise + fall
-  float band = sum + other;
-  if (b == 0 || b == kRnnBands - 1) band *= 2;
-  return __shfl(band, (lane < kRnnBands ? lane : 0) * 2);  // lanes 0..21 pick band `lane`
+  __syncthreads();  // earlier readers of scratch are done
+  scratch[lane] = rise;
+  scratch[64 + lane] = fall;
+  __syncthreads();
+  float band = 0.0f;
+  if (lane < kRnnBands) {
+    float r = 0.0f, f = 0.0f;
+    if (lane > 0) {
+      const int k0 = c_seg_blk0[lane - 1], nk = c_seg_nblk[lane - 1];
+      for (int k = 0; k < nk; ++k) r += scratch[k0 + k];
+    }
+    if (lane < kRnnBands - 1) {
+      const int k0 = c_seg_blk0[lane], nk = c_seg_nblk[lane];
+      for (int k = 0; k < nk; ++k) f += scratch[64 + k0 + k];
+    }
+    band = r + f;
+    if (lane == 0 || lane == kRnnBands - 1) band *= 2;
+  }
+  return band;
 }
 
 // interp_band_gain value at one bin
@@ -328,8 +396,9 @@ __device__ __forceinline__ float interp_gain(const float *bandE, const float *fr
 // ============================================================================== analysis, part 1
 // One wave per (frame, stream): window, forward transform, band energies.  Fully parallel.
 struct SpectrumLds {
-  float2 fa[kRnnWindow], fb[kRnnWindow];
+  float2 fa[kFftBuf], fb[kRnnWindow];
   float frac[404];
+  float bandtmp[128];
 };
 
 // Frames handled by one wave of the frame-parallel kernels: the per-wave setup (twiddles, tables) is
@@ -360,7 +429,7 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArg
     fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
     float2 *Xg = a.X + cell * kRnnFreq;
     for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fb[i];
-    const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
+    const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane, L.bandtmp);
     if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
   }
 }
@@ -707,10 +776,11 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a
 // ============================================================================== analysis, part 3
 // One wave per (frame, stream): pitch-aligned transform, band energy / correlation, their cepstral features.
 struct PitchSpecLds {
-  float2 fa[kRnnWindow], fb[kRnnWindow];
+  float2 fa[kFftBuf], fb[kRnnWindow];
   float2 X[kRnnFreq + 3];
   float frac[404];
   float Exp[kRnnBands];
+  float bandtmp[128];
 };
 
 extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppArgs a, SuppTables tb) {
@@ -746,8 +816,8 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppAr
     fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
     float2 *Pg = a.P + cell * kRnnFreq;
     for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
-    const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane);
-    float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane);
+    const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane, L.bandtmp);
+    float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane, L.bandtmp);
     if (lane < kRnnBands) {
       const float ex = rec->Ex[lane];
       exp_ = exp_ / sqrtf(.001f + ex * ep);
@@ -1002,9 +1072,10 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
 struct SynthLds {
   float frac[404];
   int32_t band_of[484];
-  float2 fa[kRnnWindow], fb[kRnnWindow];
+  float2 fa[kFftBuf], fb[kRnnWindow];
   float2 X[kRnnFreq + 3], P[kRnnFreq + 3];
   float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], g[kRnnBands], graw[kRnnBands], r[kRnnBands], norm[kRnnBands];
+  float bandtmp[128];
 };
 
 // One wave per (frame, stream): comb filter, gains, inverse transform, synthesis window.  The 960 windowed
@@ -1061,7 +1132,7 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs
       }
       __syncthreads();
       {
-        const float newE = band_accumulate_wave(L.X, L.X, L.frac, lane);
+        const float newE = band_accumulate_wave(L.X, L.X, L.frac, lane, L.bandtmp);
         if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + newE));
       }
       __syncthreads();

@@ -120,20 +120,29 @@ static void apply_window(float *x) {
 }
 
 /* ------------------------------------------------------------ band tools */
-/* Band b = R_b + F_b: R_b sums the rising ramp over band b-1's bins, F_b the falling ramp over band b's bins
- * (each left to right).  The scalar C interleaves both into one accumulator; two accumulators map to two
- * lanes on the GPU and differ from that only in the last rounding. */
+/* Band b = R_b + F_b: R_b sums the rising ramp over band b-1's bins, F_b the falling ramp over band b's bins.
+ * Evaluation order (the GPU kernels use the very same one): a band segment is cut into blocks of 8 bins, each
+ * block is summed left to right, and the block sums are added in block order.  The scalar C of RNNoise uses
+ * one running accumulator per band; this differs from it only in the last roundings. */
 static void band_accumulate(float *bandE, const cpx *X, const cpx *P) {
   float rise[NB] = {0}, fall[NB] = {0};
   for (int i = 0; i < NB - 1; ++i) {
     int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
-    for (int j = 0; j < band_size; ++j) {
-      float frac = (float)j / band_size;
-      int idx = (eband5ms[i] << 2) + j;
-      float tmp = X[idx].r * P[idx].r + X[idx].i * P[idx].i;
-      fall[i] += (1 - frac) * tmp;
-      rise[i + 1] += frac * tmp;
+    float rise_total = 0, fall_total = 0;
+    for (int k0 = 0; k0 < band_size; k0 += 8) {
+      float r = 0, f = 0;
+      for (int j = k0; j < k0 + 8 && j < band_size; ++j) {
+        float frac = (float)j / band_size;
+        int idx = (eband5ms[i] << 2) + j;
+        float tmp = X[idx].r * P[idx].r + X[idx].i * P[idx].i;
+        f += (1 - frac) * tmp;
+        r += frac * tmp;
+      }
+      rise_total += r;
+      fall_total += f;
     }
+    fall[i] = fall_total;
+    rise[i + 1] = rise_total;
   }
   for (int i = 0; i < NB; ++i) bandE[i] = rise[i] + fall[i];
   bandE[0] *= 2;
