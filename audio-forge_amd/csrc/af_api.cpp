@@ -101,7 +101,8 @@ struct af_engine {
   hipStream_t last_stream = nullptr;
   af::SuppressorHost supp;
   hipStream_t aux_stream = nullptr;                      // chain launches while the suppressor fills the chip
-  hipStream_t pre_stream = nullptr;                      // the suppressor's sample-serial pre-pass, one window ahead
+  hipStream_t pre_stream = nullptr;                      // the suppressor's sample-serial pre-pass, two windows ahead
+  hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
   std::vector<hipEvent_t> sync_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
   int supp_window_frames = 50;
@@ -471,6 +472,7 @@ void af_engine_destroy(af_engine *e) {
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
+  if (e->ana_stream) (void)hipStreamDestroy(e->ana_stream);
   if (e->supp.d_blob || e->supp.d_state || e->supp.d_xh) {
     (void)hipSetDevice(e->device);
     e->supp.release_all();
@@ -717,12 +719,14 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
 
   // ---- RNNoise suppressor ahead of the chain (realtime order, dsp_loop.rs:1222-1250,1521-1599).
-  // The call is cut into windows of frames and runs as a three-stage pipeline over them:
-  //   pre stream    : window w+1's sample-serial pre-pass (front end + model-input high-pass; 64 waves whose
+  // The call is cut into windows of frames and runs as a four-stage pipeline over them, one HIP stream each:
+  //   pre stream    : window w+2's sample-serial pre-pass (front end + model-input high-pass; 64 waves whose
   //                   duration is set by recurrence latency, so it costs the chip almost nothing)
-  //   caller stream : window w's frame-parallel suppressor kernels (these fill the chip)
+  //   analysis      : window w+1's spectra and pitch search (the pitch kernel walks each stream's frames in
+  //                   order, one wave per stream: latency bound, it leaves most issue slots free)
+  //   caller stream : window w's pitch-aligned spectra, network, resynthesis, overlap-add
   //   chain stream  : window w-1's chain launch (64 streams per workgroup, a quarter of the CUs at batch 4096)
-  // ordered by events; the two model-input buffers alternate between consecutive windows.
+  // ordered by events; buffers that cross a stage boundary rotate (af_suppressor_host.hpp).
   if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
   if (n_samples % af::kRnnFrame != 0)
     return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
@@ -749,6 +753,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
+  if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
   int64_t blocks_done = 0;
   size_t ev_index = 0;
   auto next_event = [&](hipEvent_t *out_ev) -> int {
@@ -766,15 +771,17 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ev, stream));
     AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
     AF_HIP(hipStreamWaitEvent(e->pre_stream, ev, 0));
+    AF_HIP(hipStreamWaitEvent(e->ana_stream, ev, 0));
   }
+  constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
     af::SuppArgs sa{};
     sa.in = in;
     sa.out = out;
-    sa.xh = e->supp.d_xh + (size_t)(index & 1) * e->supp.xh_floats;
-    sa.X = e->supp.d_X;
+    sa.xh = e->supp.d_xh + (size_t)(index % kXh) * e->supp.xh_floats;
+    sa.X = e->supp.d_X + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
     sa.P = e->supp.d_P;
-    sa.rec = e->supp.d_rec;
+    sa.rec = e->supp.d_rec + (size_t)(index & 1) * e->supp.ws_cells;
     sa.state = e->supp.d_state;
     sa.stream_stride = stream_stride;
     sa.n_streams = e->n_streams;
@@ -793,30 +800,49 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     sa.f64_pre_z1 = af::kPreZ1;
     sa.f32_dc_x1 = af::kDcX1;
     if (index > 0) {  // history = tail of the previous window's buffer (all earlier windows are `window` frames long)
-      sa.xh_prev = e->supp.d_xh + (size_t)((index - 1) & 1) * e->supp.xh_floats;
+      sa.xh_prev = e->supp.d_xh + (size_t)((index - 1) % kXh) * e->supp.xh_floats;
       sa.xh_prev_stride = af::kPitchBuf + window * af::kRnnFrame;
     }
     return sa;
   };
-  std::vector<hipEvent_t> window_done;  // window w's frame-parallel kernels finished (its model-input buffer is free)
-  int64_t index = 0;
-  for (int64_t f0 = 0; f0 < frames; f0 += window, ++index) {
-    const int64_t nf = std::min<int64_t>(window, frames - f0);
-    const af::SuppArgs sa = window_args(f0, nf, index);
-    // pre-pass of this window, possibly while the previous window's kernels still run
-    if (index >= 2) AF_HIP(hipStreamWaitEvent(e->pre_stream, window_done[index - 2], 0));
-    AF_HIP(af::launch_suppressor_prefilter(sa, e->pre_stream));
-    hipEvent_t ev_pre;
-    if (int rc = next_event(&ev_pre)) return rc;
-    AF_HIP(hipEventRecord(ev_pre, e->pre_stream));
-    AF_HIP(hipStreamWaitEvent(stream, ev_pre, 0));
-    AF_HIP(af::launch_suppressor_window(sa, e->supp.tables, e->supp.dw, stream));
+  const int64_t n_windows = (frames + window - 1) / window;
+  std::vector<hipEvent_t> pre_done(n_windows), ana_done(n_windows), syn_done(n_windows);
+  for (int64_t w = 0; w < n_windows; ++w) {
+    if (int rc = next_event(&pre_done[w])) return rc;
+    if (int rc = next_event(&ana_done[w])) return rc;
+    if (int rc = next_event(&syn_done[w])) return rc;
+  }
+  // Stages are enqueued in pipeline order (the pre-pass two windows and the analysis one window ahead of the
+  // synthesis), so that every event a stage waits on has been recorded before the wait is enqueued.
+  auto enqueue_pre = [&](int64_t w) -> int {
+    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
+    if (w >= kXh) AF_HIP(hipStreamWaitEvent(e->pre_stream, syn_done[w - kXh], 0));  // its model-input buffer is free
+    AF_HIP(af::launch_suppressor_prefilter(window_args(f0, nf, w), e->pre_stream));
+    AF_HIP(hipEventRecord(pre_done[w], e->pre_stream));
+    return AF_OK;
+  };
+  auto enqueue_ana = [&](int64_t w) -> int {
+    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
+    AF_HIP(hipStreamWaitEvent(e->ana_stream, pre_done[w], 0));
+    if (w >= 2) AF_HIP(hipStreamWaitEvent(e->ana_stream, syn_done[w - 2], 0));  // its spectrum / record buffers are free
+    AF_HIP(af::launch_suppressor_analysis(window_args(f0, nf, w), e->supp.tables, e->ana_stream));
+    AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));
+    return AF_OK;
+  };
+  for (int64_t w = 0; w < std::min<int64_t>(2, n_windows); ++w)
+    if (int rc = enqueue_pre(w)) return rc;
+  if (int rc = enqueue_ana(0)) return rc;
+  for (int64_t w = 0; w < n_windows; ++w) {
+    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
+    AF_HIP(hipStreamWaitEvent(stream, ana_done[w], 0));
+    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, stream));
+    AF_HIP(hipEventRecord(syn_done[w], stream));
     e->last_launches += 7;
-    hipEvent_t ev;
-    if (int rc = next_event(&ev)) return rc;
-    AF_HIP(hipEventRecord(ev, stream));
-    window_done.push_back(ev);
-    AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
+    if (w + 2 < n_windows)
+      if (int rc = enqueue_pre(w + 2)) return rc;
+    if (w + 1 < n_windows)
+      if (int rc = enqueue_ana(w + 1)) return rc;
+    AF_HIP(hipStreamWaitEvent(e->aux_stream, syn_done[w], 0));
     const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
     int rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,

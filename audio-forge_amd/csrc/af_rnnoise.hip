@@ -1209,11 +1209,17 @@ hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Everything downstream of the pre-pass for one window.
-hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
+// Analysis of one window: spectra, then pitch + cepstral features (frames in order per stream).
+hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
+  return hipGetLastError();
+}
+
+// The rest of the window: pitch-aligned spectra, the network, resynthesis, overlap-add.
+hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
+  const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
   hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, stream, a, tb);

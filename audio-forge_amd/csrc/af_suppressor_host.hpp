@@ -11,7 +11,8 @@
 
 namespace af {
 
-hipError_t launch_suppressor_window(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream);
+hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream);
+hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream);
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
 
 // int8 network weights in the layout of the public RNNoise model (dense: [in][out]; GRU: [in][3*units],
@@ -75,7 +76,9 @@ struct SuppressorHost {
   SuppTables tables{};
   float *d_state = nullptr;  // [streams][SuppState::kCount]
   float *d_xh = nullptr;
-  size_t xh_floats = 0;  // floats per model-input buffer (there are two)
+  static constexpr int kXhBuffers = 3;
+  size_t xh_floats = 0;  // floats per model-input buffer
+  size_t ws_cells = 0;   // (frame, stream) cells per spectrum / record buffer
   float2 *d_X = nullptr, *d_P = nullptr;
   SuppFrameRec *d_rec = nullptr;
   int ws_frames = 0, ws_streams = 0;
@@ -201,12 +204,15 @@ struct SuppressorHost {
     release_workspace();
     hipError_t err;
     const size_t cells = (size_t)frames * n_streams;
-    // two model-input buffers: the pre-pass of window w+1 fills one while window w's kernels read the other
-    if ((err = hipMalloc(&d_xh, sizeof(float) * 2 * (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame))) != hipSuccess) return err;
+    // The windows of a call run as a pipeline (pre-pass | analysis | synthesis), so the buffers that cross a
+    // stage boundary exist several times: the model input lives from the pre-pass to the synthesis (3 windows
+    // in flight), spectra and frame records from the analysis to the synthesis (2).
     xh_floats = (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame);
-    if ((err = hipMalloc(&d_X, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
+    ws_cells = cells;
+    if ((err = hipMalloc(&d_xh, sizeof(float) * kXhBuffers * xh_floats)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_X, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_P, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
-    if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * cells)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * 2 * cells)) != hipSuccess) return err;
     ws_frames = frames;
     ws_streams = n_streams;
     return hipSuccess;
