@@ -23,6 +23,9 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
+hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
+                             hipStream_t stream);
+size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_merge_side_stats(BlockStats *rows, const BlockStats *input_rows, const BlockStats *deesser_rows,
                                    int64_t n, hipStream_t stream);
 hipError_t launch_resample(const double *in, double *out, const ResamplePos *pos, const double *table, int64_t n_in,
@@ -298,8 +301,13 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
   const bool ring_fits = af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   const bool auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
+  const bool eq_first_deesser = (run.flags & af::kFlagDeesser) && (run.flags & af::kFlagEqBeforeDeesser);
+  const bool quad_ok = !auto_makeup && !eq_first_deesser &&
+                       af::quad_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   int kernel = e->kernel;
-  if (kernel == AF_KERNEL_AUTO) kernel = ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM;
+  if (kernel == AF_KERNEL_AUTO) kernel = quad_ok ? AF_KERNEL_QUAD : (ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM);
+  if (kernel == AF_KERNEL_QUAD && !quad_ok)
+    return fail(AF_ERR_UNSUPPORTED, "the quad kernel does not build auto-makeup or the EQ-before-de-esser order; use AF_KERNEL_PHASED");
   if (kernel == AF_KERNEL_PHASED && !ring_fits)
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
   if (auto_makeup && kernel != AF_KERNEL_PHASED)
@@ -408,7 +416,12 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
       e->uploaded_valid = true;
     }
-    AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
+    if (kernel == AF_KERNEL_QUAD) {
+      AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));  // fields are written by their tokens
+      AF_HIP(af::launch_chain_quad(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant / 100, stream));
+    } else {
+      AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
+    }
     e->last_launches += 1;
   }
   if (input_rows || deesser) {
@@ -645,7 +658,7 @@ int af_suppressor_debug_read(af_engine *e, int32_t frame, int32_t stream, float 
 
 int af_engine_set_kernel(af_engine *e, int32_t kernel) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_PHASED) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_QUAD) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   e->kernel = kernel;
   return AF_OK;
 }

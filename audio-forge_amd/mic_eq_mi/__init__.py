@@ -8,7 +8,7 @@ falls back to a CPU implementation.
 from __future__ import annotations
 
 from . import _lib
-from ._lib import KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, LAYOUT_STREAM_MAJOR, LAYOUT_TIME_MAJOR
+from ._lib import KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD, LAYOUT_STREAM_MAJOR, LAYOUT_TIME_MAJOR
 
 _CORE_IMPORT_ERROR = None
 try:
@@ -47,4 +47,4 @@ for _name in _OPERATORS:
 Engine = getattr(_core_module, "Engine", None) if _core_module is not None else None
 
 __all__ = ["CORE_AVAILABLE", "Engine", *_OPERATORS, "LAYOUT_STREAM_MAJOR", "LAYOUT_TIME_MAJOR", "KERNEL_AUTO",
-           "KERNEL_LANE_PER_STREAM", "KERNEL_PHASED"]
+           "KERNEL_LANE_PER_STREAM", "KERNEL_PHASED", "KERNEL_QUAD"]

@@ -21,7 +21,7 @@ AF_ERR_UNSUPPORTED = -5
 
 LAYOUT_STREAM_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
-KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED = 0, 1, 2
+KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD = 0, 1, 2, 3
 
 
 class EqBandConfig(C.Structure):

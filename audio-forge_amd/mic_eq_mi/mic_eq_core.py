@@ -65,12 +65,16 @@ class Engine:
         self.device = int(device)
 
     def _apply_variant_override(self) -> None:
-        """AF_KERNEL_VARIANT=lane | ring-<waves>x<chunk> pins the kernel (tests and tuning runs)."""
+        """AF_KERNEL_VARIANT=lane | quad | ring-<waves>x<chunk> pins the kernel (tests and tuning runs)."""
         import os
 
         variant = os.environ.get("AF_KERNEL_VARIANT", "")
         if variant == "lane":
             _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_LANE_PER_STREAM))
+        elif variant.startswith("quad"):  # quad | quad-<waves>
+            _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_QUAD))
+            if "-" in variant:
+                _lib.check(self._lib.af_engine_set_ring_variant(self._h, int(variant.split("-")[1]), 4))
         elif variant.startswith("ring-"):
             waves, chunk = (int(v) for v in variant[5:].split("x"))
             _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_PHASED))

@@ -18,7 +18,7 @@ MAX_ABS = 5e-7
 MAX_RMS = 5e-8
 
 
-@pytest.fixture(scope="module", params=["ring-16x4", "lane"])
+@pytest.fixture(scope="module", params=["quad", "ring-16x4", "lane"])
 def mi(request):
     import mic_eq_mi
 
@@ -100,7 +100,7 @@ def test_golden_downstream_chain_kat_on_gpu(mi, oracle):
 def test_deesser_orders_and_manual_mode(mi, oracle, eq_first, auto):
     """Both stage orders (routing.rs eq_before_deesser), auto and threshold/ratio modes, moved detector
     band (a pending coefficient crossfade on the nine de-esser filters), ragged batch and block sizes."""
-    if eq_first and os.environ["AF_KERNEL_VARIANT"] == "lane":
+    if eq_first and os.environ["AF_KERNEL_VARIANT"] in ("lane", "quad"):
         pytest.skip("EQ-before-de-esser needs the ring kernel's pre-pass")
     L = oracle.lib()
     n_streams, n = 67, 48_000 + 333

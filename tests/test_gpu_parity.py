@@ -20,7 +20,7 @@ MAX_ABS = 2e-7
 MAX_RMS = 2e-8
 
 
-@pytest.fixture(scope="module", params=["ring-8x4", "ring-16x4", "ring-16x2", "lane"])
+@pytest.fixture(scope="module", params=["quad", "quad-8", "ring-8x4", "ring-16x4", "ring-16x2", "lane"])
 def mi(request):
     """Every test runs once per kernel variant (selected through AF_KERNEL_VARIANT)."""
     import os
