@@ -77,6 +77,7 @@ struct af_engine {
   int64_t last_blocks = 0;
   double last_kernel_ms = 0.0;
   int last_launches = 0;
+  int last_kernel_used = 0;  // AF_KERNEL_* of the most recent chain launch
 
   af::ChainParams host_params{};
   af::ChainParams uploaded{};   // what d_params currently holds
@@ -305,13 +306,21 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   const bool quad_ok = !auto_makeup && !eq_first_deesser &&
                        af::quad_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   int kernel = e->kernel;
-  if (kernel == AF_KERNEL_AUTO) kernel = quad_ok ? AF_KERNEL_QUAD : (ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM);
+  if (kernel == AF_KERNEL_AUTO) {
+    // Kernel 2 (64 streams per workgroup) spends the fewest issue slots per stream-sample; kernel 3 (16 streams per
+    // workgroup) spends ~1.3x more but reaches four times as many CUs.  So: kernel 3 when the batch alone cannot
+    // fill the chip and nothing else wants the idle CUs; kernel 2 when the suppressor's kernels run alongside.
+    const bool chip_has_room = !e->supp.enabled && (e->n_streams + 63) / 64 < 256;
+    kernel = (quad_ok && (chip_has_room || !ring_fits)) ? AF_KERNEL_QUAD
+             : (ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM);
+  }
   if (kernel == AF_KERNEL_QUAD && !quad_ok)
     return fail(AF_ERR_UNSUPPORTED, "the quad kernel does not build auto-makeup or the EQ-before-de-esser order; use AF_KERNEL_PHASED");
   if (kernel == AF_KERNEL_PHASED && !ring_fits)
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
   if (auto_makeup && kernel != AF_KERNEL_PHASED)
     return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
+  e->last_kernel_used = kernel;
   const bool deesser = (run.flags & af::kFlagDeesser) != 0;
   const bool eq_first = (run.flags & af::kFlagEqBeforeDeesser) != 0;
   const uint32_t front_flags = af::kFlagInputScrub | af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
@@ -418,7 +427,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     }
     if (kernel == AF_KERNEL_QUAD) {
       AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));  // fields are written by their tokens
-      AF_HIP(af::launch_chain_quad(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant / 100, stream));
+      AF_HIP(af::launch_chain_quad(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant ? e->ring_variant / 100 : 12, stream));
     } else {
       AF_HIP(af::launch_chain_lane(a, run.lim.lookahead_samples, stream));
     }
@@ -670,6 +679,7 @@ int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk) {
   e->ring_variant = v;
   return AF_OK;
 }
+int af_engine_last_kernel(const af_engine *e) { return e ? e->last_kernel_used : 0; }
 int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
   e->timing = on != 0;

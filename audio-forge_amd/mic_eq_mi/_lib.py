@@ -128,6 +128,7 @@ SIGNATURES = {
     "af_engine_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(_i32)]),
     "af_engine_last_stage_ms": (C.c_int, [_vp, _dp, _dp]),
     # product resampler
+    "af_engine_last_kernel": (C.c_int, [_vp]),
     "af_resampler_calculate_cutoff": (C.c_int, [_i32, _i32, C.POINTER(C.c_float)]),
     "af_resampler_create": (C.c_int, [C.c_uint32, C.c_uint32, _i64, _i32, _i32, _i32, C.POINTER(_vp)]),
     "af_resampler_destroy": (None, [_vp]),
@@ -147,7 +148,7 @@ SIGNATURES = {
 # entry points whose return value is data, not an af_status
 VALUE_FUNCTIONS = {
     "af_version", "af_last_error", "af_device_count", "af_engine_n_streams", "af_limiter_ceiling_db",
-    "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy",
+    "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy", "af_engine_last_kernel",
     "af_resampler_destroy", "af_resampler_output_delay", "af_resampler_expected_frames", "af_resampler_sinc_len",
 }
 

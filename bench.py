@@ -77,6 +77,25 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
     return out
 
 
+def pmc_traffic(kernel_name: str, streams: int, samples_per_launch: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected separately, gfx950 correction applied; profiles/README.md), when that profile was taken
+    at this launch shape; None otherwise (counters cannot be read from inside this script)."""
+    path = ROOT / "profiles" / "r01_pmc_traffic.json"
+    try:
+        prof = json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None
+    shape = prof.get("launch_shape", {})
+    if shape.get("streams") != streams or shape.get("samples_per_launch") != samples_per_launch:
+        return None
+    base = kernel_name.split("<")[0]
+    for name, row in prof.get("kernels", {}).items():
+        if base in name and row.get("traffic_bytes_per_launch"):
+            return float(row["traffic_bytes_per_launch"])
+    return None
+
+
 def cpu_baseline(seconds: float, full: bool, budget_s: float = 15.0) -> dict:
     """The oracle (CPU restatement of rust-core; the Rust reference cannot be built here) on 1 host thread."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -209,11 +228,16 @@ def main() -> None:
     total_frames = int(merged["samples"])
     value = total_frames / elapsed_max
 
-    kernel_name = "chain_lane_kernel" if args.variant == "lane" or args.kernel == 1 else "chain_ring_kernel<" + (args.variant[5:] if args.variant.startswith("ring-") else "16x4") + ">"
+    used = int(engine._lib.af_engine_last_kernel(engine._h))
+    ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
+    quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
+    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on this stream)
-        avg_kernel_s = float(np.mean(chain_ms)) / 1000.0
-        frames_per_launch = streams * n
+        # (with the suppressor on the chain runs once per 50-frame window, so a step holds several launches)
+        launches = max(1, n // (50 * 480)) if full and n % (50 * 480) == 0 else 1
+        avg_kernel_s = float(np.mean(chain_ms)) / 1000.0 / launches
+        frames_per_launch = streams * n // launches
         achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         line = {
             "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain",
@@ -240,8 +264,8 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, streams, n // launches),
+                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
             },
             "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),

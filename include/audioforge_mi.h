@@ -208,10 +208,14 @@ int64_t af_engine_last_block_count(const af_engine *e);
 int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capacity);
 /* total samples per stream processed since create/reset */
 int64_t af_engine_samples_processed(const af_engine *e);
-/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO */
+/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: AF_KERNEL_QUAD (16 streams per workgroup)
+ * when the batch alone cannot fill the chip, AF_KERNEL_PHASED (64 streams per workgroup) otherwise and whenever
+ * auto-makeup or the EQ-before-de-esser order need its pre-pass mode */
 int af_engine_set_kernel(af_engine *e, int32_t kernel);
 /* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
  * (built: 16x4, 16x2, 12x4, 12x2, 8x4, 8x2; 0,0 = default) */
+/* AF_KERNEL_* the most recent chain launch used; VALUE, not a status */
+int af_engine_last_kernel(const af_engine *e);
 int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk);
 /* HIP-event timing of the kernels launched by the last process call, in milliseconds,
  * measured on the stream the kernels ran on (0 when timing is disabled) */
