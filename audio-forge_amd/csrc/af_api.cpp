@@ -32,6 +32,9 @@ hipError_t launch_resample(const double *in, double *out, const ResamplePos *pos
                            int64_t n_out, int64_t in_stride, int64_t out_stride, int32_t n_streams, int32_t sinc_len,
                            double ratio, hipStream_t stream);
 int resample_segment_outputs(double ratio, int sinc_len);
+hipError_t launch_kweight_energy(const float *audio, double *partial, int32_t *non_finite, const double b[5],
+                                 const double a5[5], int64_t n_samples, int64_t stride, int64_t n100, int32_t n_streams,
+                                 int32_t s100, hipStream_t stream);
 hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32, const float *in, float *out,
                           BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
@@ -1194,6 +1197,110 @@ int af_resampler_last_kernel_ms(af_resampler *r, double *ms) {
   AF_HIP(hipEventElapsedTime(&t, r->ev0, r->ev1));
   *ms = t;
   return AF_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// measure_integrated_loudness (lib.rs:290-298 over dsp/loudness.rs:43-83)
+namespace {
+// ebur128 `Mode::HISTOGRAM`: 1000 bins of 0.1 LU from -70 LUFS; blocks are represented by their bin's centre
+double hist_energy(int i) { return std::pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0); }
+double hist_boundary(int i) { return std::pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0); }
+size_t find_histogram_index(double energy) {
+  size_t lo = 0, hi = 1000;
+  do {
+    const size_t mid = (lo + hi) / 2;
+    if (energy >= hist_boundary((int)mid)) lo = mid; else hi = mid;
+  } while (hi - lo != 1);
+  return lo;
+}
+// 400 ms blocks every 100 ms, absolute gate -70 LUFS, relative gate -10 LU; false when nothing passes the gates
+bool gated_loudness(const double *part, int64_t n100, int64_t s100, double *lufs) {
+  std::vector<uint64_t> counts(1000, 0);
+  const double frames = (double)(s100 * 4);
+  for (int64_t b = 0; b + 4 <= n100; ++b) {
+    const double energy = (((part[b] + part[b + 1]) + part[b + 2]) + part[b + 3]) / frames;
+    if (energy >= hist_boundary(0)) counts[find_histogram_index(energy)]++;
+  }
+  double rel = 0.0;
+  uint64_t above = 0;
+  for (int i = 0; i < 1000; ++i) { rel += (double)counts[i] * hist_energy(i); above += counts[i]; }
+  if (!above) return false;
+  rel /= (double)above;
+  rel *= std::pow(10.0, -10.0 / 10.0);
+  size_t start;
+  if (rel < hist_boundary(0)) start = 0;
+  else { start = find_histogram_index(rel); if (rel > hist_energy((int)start)) ++start; }
+  double gated = 0.0;
+  above = 0;
+  for (size_t i = start; i < 1000; ++i) { gated += (double)counts[i] * hist_energy((int)i); above += counts[i]; }
+  if (!above) return false;
+  gated /= (double)above;
+  *lufs = 10.0 * (std::log(gated) / std::log(10.0)) - 0.691;
+  return std::isfinite(*lufs);
+}
+}  // namespace
+
+extern "C" {
+
+int af_measure_integrated_loudness_device(const float *d_audio, int64_t n_samples, int32_t n_streams, int64_t stream_stride,
+                                          uint32_t sample_rate, int32_t device, double *lufs, int32_t *status) {
+  // validate_sample_rate, loudness.rs:36-41
+  static const uint32_t rates[] = {8000, 16000, 32000, 44100, 48000, 88200, 96000};
+  bool rate_ok = false;
+  for (uint32_t r : rates) rate_ok |= r == sample_rate;
+  if (!rate_ok) return fail(AF_ERR_INVALID_ARGUMENT, "Invalid sample rate: %u", sample_rate);
+  if (n_samples <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "Invalid audio: at least one sample is required");
+  if (n_streams <= 0 || !d_audio || !lufs) return fail(AF_ERR_INVALID_ARGUMENT, "null or empty batch");
+  if (stream_stride < n_samples) return fail(AF_ERR_INVALID_ARGUMENT, "stream_stride must cover n_samples");
+  AF_HIP(hipSetDevice(device));
+  double b[5], a[5];
+  af::kweighting_design((double)sample_rate, b, a);
+  const int64_t s100 = ((int64_t)sample_rate + 5) / 10, n100 = n_samples / s100;
+  double *d_part = nullptr;
+  int32_t *d_bad = nullptr;
+  AF_HIP(hipMalloc(&d_part, sizeof(double) * std::max<int64_t>(1, n100) * n_streams));
+  AF_HIP(hipMalloc(&d_bad, sizeof(int32_t) * n_streams));
+  hipError_t err = af::launch_kweight_energy(d_audio, d_part, d_bad, b, a, n_samples, stream_stride, n100, n_streams, (int32_t)s100, nullptr);
+  std::vector<double> part((size_t)std::max<int64_t>(1, n100) * n_streams);
+  std::vector<int32_t> bad(n_streams);
+  if (err == hipSuccess) err = hipMemcpy(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost);
+  if (err == hipSuccess) err = hipMemcpy(bad.data(), d_bad, sizeof(int32_t) * n_streams, hipMemcpyDeviceToHost);
+  (void)hipFree(d_part);
+  (void)hipFree(d_bad);
+  if (err != hipSuccess) return fail(AF_ERR_BACKEND, "integrated loudness failed: %s", hipGetErrorString(err));
+  int worst = AF_OK;
+  for (int32_t s = 0; s < n_streams; ++s) {
+    int st = AF_OK;
+    double v = -HUGE_VAL;
+    if (bad[s]) st = AF_ERR_NON_FINITE;
+    else if (!gated_loudness(part.data() + (size_t)s * std::max<int64_t>(1, n100), n100, s100, &v)) st = AF_ERR_UNSUPPORTED;
+    lufs[s] = v;
+    if (status) status[s] = st;
+    if (st != AF_OK && worst == AF_OK) worst = st;
+  }
+  if (worst == AF_ERR_NON_FINITE) return fail(worst, "Invalid audio: samples must be finite");
+  if (worst == AF_ERR_UNSUPPORTED)
+    return fail(AF_ERR_INVALID_ARGUMENT, "Loudness measurement failed: audio did not produce a finite gated loudness");
+  return AF_OK;
+}
+
+int af_measure_integrated_loudness_host(const float *audio, int64_t n_samples, int32_t n_streams, int64_t stream_stride,
+                                        uint32_t sample_rate, int32_t device, double *lufs, int32_t *status) {
+  if (!audio && n_samples > 0) return fail(AF_ERR_INVALID_ARGUMENT, "audio is null");
+  if (n_samples <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "Invalid audio: at least one sample is required");
+  if (n_streams <= 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_streams must be positive");
+  AF_HIP(hipSetDevice(device));
+  float *d_audio = nullptr;
+  AF_HIP(hipMalloc(&d_audio, sizeof(float) * (size_t)n_samples * n_streams));
+  hipError_t err = hipMemcpy2D(d_audio, sizeof(float) * n_samples, audio, sizeof(float) * stream_stride, sizeof(float) * n_samples,
+                               n_streams, hipMemcpyHostToDevice);
+  int rc = AF_OK;
+  if (err != hipSuccess) rc = fail(AF_ERR_BACKEND, "hipMemcpy2D failed: %s", hipGetErrorString(err));
+  else rc = af_measure_integrated_loudness_device(d_audio, n_samples, n_streams, n_samples, sample_rate, device, lufs, status);
+  (void)hipFree(d_audio);
+  return rc;
 }
 
 }  // extern "C"

@@ -755,3 +755,41 @@ def simulate_product_resampler(samples: Sequence[float], input_rate: int, output
                                                                              chunk_size, sinc_len, window)
     per_block = int(round(kernel_ms * 1e6 / max(blocks, 1)))
     return out[0].tolist(), int(delay), int(expected), [per_block] * int(blocks)
+
+
+# ------------------------------------------------------------------ integrated loudness
+LOUDNESS_SAMPLE_RATES = (8000, 16000, 32000, 44100, 48000, 88200, 96000)  # loudness.rs:36-41
+
+
+def measure_integrated_loudness_batch(audio: np.ndarray, sample_rate: int, device: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """[n_streams, n] float32 -> (LUFS per stream, status per stream: 0 ok, -3 non-finite, -5 nothing passed the gates)."""
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("audio must be [n_streams, n]")
+    if int(sample_rate) not in LOUDNESS_SAMPLE_RATES:
+        raise ValueError(f"Invalid sample rate: {sample_rate}")
+    if a.shape[1] == 0:
+        raise ValueError("Invalid audio: at least one sample is required")
+    lufs = np.zeros(a.shape[0], dtype=np.float64)
+    status = np.zeros(a.shape[0], dtype=np.int32)
+    rc = _lib.load().af_measure_integrated_loudness_host(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0], a.shape[1],
+                                                         int(sample_rate), int(device), lufs.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         status.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc == _lib.AF_ERR_BACKEND:
+        _lib.check(rc)
+    return lufs, status
+
+
+def measure_integrated_loudness(audio, sample_rate: int) -> float:
+    """lib.rs:290-298: gated BS.1770 loudness (LUFS) of one clip; ValueError like the reference's PyValueError."""
+    a = _audio_1d(audio)
+    if int(sample_rate) not in LOUDNESS_SAMPLE_RATES:
+        raise ValueError(f"Invalid sample rate: {sample_rate}")
+    if a.size == 0:
+        raise ValueError("Invalid audio: at least one sample is required")
+    lufs, status = measure_integrated_loudness_batch(a.reshape(1, -1), sample_rate)
+    if status[0] == _lib.AF_ERR_NON_FINITE:
+        raise ValueError("Invalid audio: samples must be finite")
+    if status[0] != 0:
+        raise ValueError("Loudness measurement failed: audio did not produce a finite gated loudness")
+    return float(lufs[0])

@@ -261,6 +261,19 @@ int af_resampler_process_host(af_resampler *r, const double *in, double *out, in
 /* HIP-event time of the last launch */
 int af_resampler_last_kernel_ms(af_resampler *r, double *ms);
 
+/* ---- integrated loudness ------------------------------------------------------------------
+ * measure_integrated_loudness (rust-core/src/lib.rs:290-298 over dsp/loudness.rs:43-83): BS.1770 gated loudness of
+ * whole clips, ebur128 `Mode::I | Mode::HISTOGRAM`, mono.  One value per stream; `status` (optional, [n_streams])
+ * holds AF_OK, AF_ERR_NON_FINITE ("samples must be finite") or AF_ERR_UNSUPPORTED (nothing passed the gates:
+ * "audio did not produce a finite gated loudness"); the call returns the first failure.  Sample rates:
+ * loudness.rs:36-41. */
+int af_measure_integrated_loudness_device(const float *d_audio, int64_t n_samples, int32_t n_streams,
+                                          int64_t stream_stride, uint32_t sample_rate, int32_t device,
+                                          double *lufs, int32_t *status);
+int af_measure_integrated_loudness_host(const float *audio, int64_t n_samples, int32_t n_streams,
+                                        int64_t stream_stride, uint32_t sample_rate, int32_t device,
+                                        double *lufs, int32_t *status);
+
 /* ---- stateless helpers ----------------------------------------------------------- */
 /* eq_magnitude_response, lib.rs:99-150 (legacy (freq, gain_db, q) x 10 bands) */
 int af_eq_magnitude_response(const double *frequencies_hz, size_t n, const double bands[10][3],

@@ -2154,40 +2154,65 @@ int afo_simulate_auto_makeup_control(const float *audio, size_t n, double sample
   return 0;
 }
 
-/* lib.rs:290-298 over dsp/loudness.rs:43-83 (ebur128 Mode::I, gated; spec-restated, unpinned) */
+/* lib.rs:290-298 over dsp/loudness.rs:43-83: ebur128 `Mode::I | Mode::HISTOGRAM`, mono (crate not vendored:
+ * restated from the published libebur128 design the crate ports; parity unpinned).
+ *   - K-weighted signal, 400 ms gating blocks every 100 ms ((rate + 5) / 10 frames);
+ *   - HISTOGRAM mode: a block above the absolute gate (-70 LUFS) is counted in one of 1000 bins of 0.1 LU and from
+ *     then on represented by its bin's centre energy; relative gate = mean of those - 10 LU; the result is the
+ *     mean bin energy from the first bin at or above the relative gate.
+ * A block's energy is accumulated as four 100 ms partial sums added oldest first (the GPU kernel produces the
+ * partial sums; libebur128 walks its ring in storage order -- the two differ in the last bit at most). */
+static double hist_energy(int i) { return pow(10.0, ((double)i / 10.0 - 69.95 + 0.691) / 10.0); }
+static double hist_boundary(int i) { return pow(10.0, ((double)i / 10.0 - 70.0 + 0.691) / 10.0); }
+static size_t find_histogram_index(double energy) {
+  size_t lo = 0, hi = 1000;
+  do {
+    size_t mid = (lo + hi) / 2;
+    if (energy >= hist_boundary((int)mid)) lo = mid; else hi = mid;
+  } while (hi - lo != 1);
+  return lo;
+}
+/* gating over 100 ms partial sums of y^2 (n100 of them, each over s100 frames) */
+int afo_gated_loudness_from_partial_sums(const double *part, size_t n100, size_t s100, double *lufs) {
+  unsigned long counts[1000];
+  memset(counts, 0, sizeof counts);
+  const double frames = (double)(s100 * 4);
+  for (size_t b = 0; b + 4 <= n100; ++b) {
+    const double energy = (((part[b] + part[b + 1]) + part[b + 2]) + part[b + 3]) / frames;
+    if (energy >= hist_boundary(0)) counts[find_histogram_index(energy)]++;
+  }
+  double rel = 0.0; unsigned long above = 0;
+  for (int i = 0; i < 1000; ++i) { rel += (double)counts[i] * hist_energy(i); above += counts[i]; }
+  if (!above) return -4;
+  rel /= (double)above;
+  rel *= pow(10.0, -10.0 / 10.0);
+  size_t start;
+  if (rel < hist_boundary(0)) start = 0;
+  else { start = find_histogram_index(rel); if (rel > hist_energy((int)start)) ++start; }
+  double gated = 0.0; above = 0;
+  for (size_t i = start; i < 1000; ++i) { gated += (double)counts[i] * hist_energy((int)i); above += counts[i]; }
+  if (!above) return -4;
+  gated /= (double)above;
+  *lufs = 10.0 * (log(gated) / log(10.0)) - 0.691;
+  return isfinite(*lufs) ? 0 : -4;
+}
 int afo_measure_integrated_loudness(const float *audio, size_t n, uint32_t sample_rate, double *lufs) {
   afo_loudness m;
   if (afo_loudness_init(&m, sample_rate)) return -1;
   if (n == 0) { afo_loudness_free(&m); return -2; }
   for (size_t i = 0; i < n; ++i)
     if (!isfinite(audio[i])) { afo_loudness_free(&m); return -3; }
-  /* 400 ms blocks with 75 % overlap (hop = 100 ms), absolute gate -70 LUFS, relative gate -10 LU */
-  size_t s100 = (sample_rate + 5) / 10, blk = s100 * 4;
-  double *y = (double *)malloc(sizeof(double) * n);
+  const size_t s100 = (sample_rate + 5) / 10, n100 = n / s100;
+  double *part = (double *)calloc(n100 ? n100 : 1, sizeof(double));
   double v[5] = {0, 0, 0, 0, 0};
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = 0; i < n100 * s100; ++i) {
     v[0] = (double)audio[i] - m.a[1] * v[1] - m.a[2] * v[2] - m.a[3] * v[3] - m.a[4] * v[4];
-    y[i] = m.b[0] * v[0] + m.b[1] * v[1] + m.b[2] * v[2] + m.b[3] * v[3] + m.b[4] * v[4];
+    const double y = m.b[0] * v[0] + m.b[1] * v[1] + m.b[2] * v[2] + m.b[3] * v[3] + m.b[4] * v[4];
     v[4] = v[3]; v[3] = v[2]; v[2] = v[1]; v[1] = v[0];
+    part[i / s100] += y * y;
   }
-  size_t nblk = n >= blk ? (n - blk) / s100 + 1 : 0;
-  double *e = (double *)malloc(sizeof(double) * (nblk ? nblk : 1));
-  for (size_t b = 0; b < nblk; ++b) {
-    double sum = 0.0;
-    for (size_t i = 0; i < blk; ++i) sum += y[b * s100 + i] * y[b * s100 + i];
-    e[b] = sum / (double)blk;
-  }
-  const double abs_gate = pow(10.0, (-70.0 + 0.691) / 10.0);
-  double sum = 0.0; size_t cnt = 0;
-  for (size_t b = 0; b < nblk; ++b) if (e[b] >= abs_gate) { sum += e[b]; cnt++; }
-  int rc = 0;
-  if (cnt == 0) { rc = -4; }
-  else {
-    double rel_gate = (sum / (double)cnt) * pow(10.0, -10.0 / 10.0);
-    sum = 0.0; cnt = 0;
-    for (size_t b = 0; b < nblk; ++b) if (e[b] >= abs_gate && e[b] >= rel_gate) { sum += e[b]; cnt++; }
-    if (cnt == 0) rc = -4; else *lufs = 10.0 * log10(sum / (double)cnt) - 0.691;
-  }
-  free(y); free(e); afo_loudness_free(&m);
+  int rc = afo_gated_loudness_from_partial_sums(part, n100, s100, lufs);
+  free(part);
+  afo_loudness_free(&m);
   return rc;
 }

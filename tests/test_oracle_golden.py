@@ -322,3 +322,18 @@ def test_fir_table_matches_reference_text_if_present():
         vals = re.findall(r"-?0x[0-9a-f.]+p[-+]?\d+", header.read_text())
         mine = np.array([float.fromhex(v) for v in vals]).reshape(4, 32).astype(np.float32)
         assert np.array_equal(mine, ref)
+
+
+def test_integrated_loudness_reference_properties(oracle):
+    """loudness.rs:222-257 on the oracle's histogram-mode gate (ebur128 not vendored: unpinned)."""
+    i = np.arange(48_000 * 8, dtype=np.float32)
+    tone = (np.float32(0.1) * np.sin(np.float32(2.0 * np.pi) * np.float32(1000.0) * i / np.float32(48_000))).astype(np.float32)
+    padded = np.concatenate([np.zeros(48_000, np.float32), tone, np.zeros(48_000, np.float32)])
+    a, b = oracle.measure_integrated_loudness(tone, 48_000), oracle.measure_integrated_loudness(padded, 48_000)
+    assert abs(a - b) < 0.2 and -24.0 < a < -22.0
+    assert abs(a - (-23.05)) < 1e-9  # a block's loudness is its 0.1 LU histogram bin's centre
+    for bad in (np.zeros(0, np.float32), np.array([np.nan], np.float32), np.zeros(48_000, np.float32)):
+        with pytest.raises(ValueError):
+            oracle.measure_integrated_loudness(bad, 48_000)
+    with pytest.raises(ValueError):
+        oracle.measure_integrated_loudness(np.array([0.1], np.float32), 12_345)
