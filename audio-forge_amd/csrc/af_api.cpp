@@ -807,6 +807,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     sa.xh = e->supp.d_xh + (size_t)(index % kXh) * e->supp.xh_floats;
     sa.X = e->supp.d_X + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
     sa.P = e->supp.d_P;
+    sa.ds = e->supp.d_ds;
     sa.rec = e->supp.d_rec + (size_t)(index & 1) * e->supp.ws_cells;
     sa.state = e->supp.d_state;
     sa.stream_stride = stream_stride;

@@ -471,26 +471,24 @@ __device__ __forceinline__ void best_pitch_scan(const float *numa, const float *
   }
 }
 
-extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a, SuppTables tb) {
-  __shared__ PitchLds L;
+// ---- pitch, part 1: everything that depends on the frame alone (wave per (frame, stream), fully parallel):
+// 2x decimation + LPC-4 whitening, coarse and fine cross-correlation search.  Leaves the whitened buffer and
+// the candidate period for part 2.
+struct PitchSearchLds {
+  float ds[kPitchBuf / 2];
+  float xc[304];
+  float numa[304], da[304];
+};
+extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ PitchSearchLds L;
   const int lane = threadIdx.x;
-  const int s = blockIdx.x;
+  const int s = (int)(blockIdx.x / a.n_frames), f = (int)(blockIdx.x % a.n_frames);
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
   const float *xh = a.xh + (int64_t)s * (kPitchBuf + n);
-  float *st = a.state + (int64_t)s * SuppState::kCount;
-  int last_period = (int)st[SuppState::kLastPeriod];
-  float last_gain = st[SuppState::kLastGain];
-  int memid = (int)st[SuppState::kMemId];
-  for (int i = lane; i < kCepsMem * kRnnBands; i += 64) (&L.ceps[0][0])[i] = st[SuppState::kCeps + i];
-  float dctcol[kRnnBands];  // column `lane` of the DCT matrix (lanes < 22)
-#pragma unroll
-  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < kRnnBands ? lane : 0)];
-  __syncthreads();
-
-  for (int f = 0; f < a.n_frames; ++f) {
+  const int64_t cell = (int64_t)f * a.n_streams + s;
+  {
     const float *pb = xh + (int64_t)(f + 1) * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
-    SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
-    if (lane < kRnnBands) L.Ex[lane] = rec->Ex[lane];
+    SuppFrameRec *rec = a.rec + cell;
     // ---------------- pitch_downsample (pitch.c): 2x decimation, LPC-4 whitening
     for (int i = lane; i < kPitchBuf / 2; i += 64)
       L.ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0]) : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
@@ -611,6 +609,40 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a
       }
       pitch_index = kPitchMax - (2 * best0 - offset);
     }
+    __syncthreads();
+    __syncthreads();
+    float *dsg = a.ds + cell * (kPitchBuf / 2);
+    for (int i = lane; i < kPitchBuf / 2; i += 64) dsg[i] = L.ds[i];
+    if (lane == 0) rec->pitch_index = pitch_index;
+  }
+}
+
+// ---- pitch, part 2: what looks at the previous frame (wave per stream, frames in order): octave-error removal
+// (remove_doubling compares with the last period and gain), the cepstral ring and the features built on it.
+extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ PitchLds L;
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x;
+  const int64_t n = (int64_t)a.n_frames * kRnnFrame;
+  const float *xh = a.xh + (int64_t)s * (kPitchBuf + n);
+  float *st = a.state + (int64_t)s * SuppState::kCount;
+  int last_period = (int)st[SuppState::kLastPeriod];
+  float last_gain = st[SuppState::kLastGain];
+  int memid = (int)st[SuppState::kMemId];
+  for (int i = lane; i < kCepsMem * kRnnBands; i += 64) (&L.ceps[0][0])[i] = st[SuppState::kCeps + i];
+  float dctcol[kRnnBands];  // column `lane` of the DCT matrix (lanes < 22)
+#pragma unroll
+  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < kRnnBands ? lane : 0)];
+  __syncthreads();
+
+  for (int f = 0; f < a.n_frames; ++f) {
+    SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
+    if (lane < kRnnBands) L.Ex[lane] = rec->Ex[lane];
+    {
+      const float *dsg = a.ds + ((int64_t)f * a.n_streams + s) * (kPitchBuf / 2);
+      for (int i = lane; i < kPitchBuf / 2; i += 64) L.ds[i] = dsg[i];
+    }
+    int pitch_index = rec->pitch_index;
     __syncthreads();
     // ---------------- remove_doubling(ds, 768, 60, 960, &pitch_index, last_period, last_gain)
     float gain;
@@ -1213,6 +1245,7 @@ hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
 hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
+  hipLaunchKernelGGL(supp_pitchsearch_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
   return hipGetLastError();
 }

@@ -79,6 +79,7 @@ struct SuppArgs {
   const float *xh_prev;       // the previous window's buffer (history source for the pre-pass), or null: use `state`
   int64_t xh_prev_stride;     // 1728 + its frame count * 480
   float2 *X, *P;              // [frame][stream][481]
+  float *ds;                  // [frame][stream][864] LPC-whitened, 2x-decimated pitch buffer (pitch part 1 -> part 2)
   SuppFrameRec *rec;          // [frame][stream]
   float *state;               // [stream][SuppState::kCount]
   int64_t stream_stride;

@@ -76,6 +76,7 @@ struct SuppressorHost {
   SuppTables tables{};
   float *d_state = nullptr;  // [streams][SuppState::kCount]
   float *d_xh = nullptr;
+  float *d_ds = nullptr;
   static constexpr int kXhBuffers = 3;
   size_t xh_floats = 0;  // floats per model-input buffer
   size_t ws_cells = 0;   // (frame, stream) cells per spectrum / record buffer
@@ -213,12 +214,15 @@ struct SuppressorHost {
     if ((err = hipMalloc(&d_X, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_P, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * 2 * cells)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_ds, sizeof(float) * cells * (kPitchBuf / 2))) != hipSuccess) return err;
     ws_frames = frames;
     ws_streams = n_streams;
     return hipSuccess;
   }
   void release_workspace() {
     (void)hipFree(d_xh);
+    (void)hipFree(d_ds);
+    d_ds = nullptr;
     (void)hipFree(d_X);
     (void)hipFree(d_P);
     (void)hipFree(d_rec);
