@@ -772,7 +772,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   // a window must hold whole control blocks, or block boundaries (hence per-block semantics) would move
   int64_t unit = 1;
   while ((unit * af::kRnnFrame) % cb != 0) ++unit;
-  int64_t window = std::max<int64_t>(unit, (e->supp_window_frames / unit) * unit);
+  int window_frames = e->supp_window_frames;
+  if (const char *env = std::getenv("AF_SUPP_WINDOW_FRAMES")) window_frames = std::max(1, std::atoi(env));  // tuning runs
+  int64_t window = std::max<int64_t>(unit, (window_frames / unit) * unit);
   const bool windows_align = frames % unit == 0 || frames <= window;
   if (!windows_align) window = frames;  // ragged tail: one window (workspace permitting)
   window = std::min<int64_t>(window, frames);

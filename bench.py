@@ -235,7 +235,8 @@ def main() -> None:
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on this stream)
         # (with the suppressor on the chain runs once per 50-frame window, so a step holds several launches)
-        launches = max(1, n // (50 * 480)) if full and n % (50 * 480) == 0 else 1
+        window = int(os.environ.get("AF_SUPP_WINDOW_FRAMES", "50")) * 480
+        launches = max(1, n // window) if full and n % window == 0 else 1
         avg_kernel_s = float(np.mean(chain_ms)) / 1000.0 / launches
         frames_per_launch = streams * n // launches
         achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
