@@ -1307,3 +1307,68 @@ int af_measure_integrated_loudness_host(const float *audio, int64_t n_samples, i
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Noise gate, expander path (dsp/gate.rs:626-637), as simulate_gate_suppressor_order drives it
+namespace af {
+struct GateArgs {
+  const float *in;
+  float *out;
+  float *gain_trace;
+  uint64_t *chatter;
+  double *state;
+  double threshold_db, attack_coeff, release_coeff, rms_coeff;
+  int64_t n_samples, stride;
+  int32_t n_streams, block, vad_mode;
+  int32_t hold_samples, window_samples, cooldown_samples, relax_samples;
+};
+hipError_t launch_gate(const GateArgs &a, hipStream_t stream);
+}  // namespace af
+
+extern "C" {
+
+int af_gate_process_host(const float *in, float *out, int64_t n_samples, int32_t n_streams, int64_t stream_stride,
+                         double threshold_db, double attack_ms, double release_ms, double sample_rate, int32_t vad_mode,
+                         int32_t trace_block, float *gain_trace, uint64_t *chatter_events, int32_t device) {
+  if (!in || !out) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
+  if (n_samples < 0 || n_streams <= 0 || stream_stride < n_samples) return fail(AF_ERR_INVALID_ARGUMENT, "bad batch shape");
+  if (!std::isfinite(sample_rate) || sample_rate <= 0.0) return fail(AF_ERR_INVALID_ARGUMENT, "sample_rate must be positive and finite");
+  if (trace_block <= 0) trace_block = 480;
+  AF_HIP(hipSetDevice(device));
+  const int64_t blocks = (n_samples + trace_block - 1) / trace_block;
+  float *d_in = nullptr, *d_trace = nullptr;
+  uint64_t *d_chatter = nullptr;
+  const size_t audio_bytes = sizeof(float) * (size_t)std::max<int64_t>(1, n_samples) * n_streams;
+  AF_HIP(hipMalloc(&d_in, audio_bytes));
+  AF_HIP(hipMalloc(&d_trace, sizeof(float) * (size_t)std::max<int64_t>(1, blocks) * n_streams));
+  AF_HIP(hipMalloc(&d_chatter, sizeof(uint64_t) * n_streams));
+  hipError_t err = hipSuccess;
+  if (n_samples > 0)
+    err = hipMemcpy2D(d_in, sizeof(float) * n_samples, in, sizeof(float) * stream_stride, sizeof(float) * n_samples, n_streams,
+                      hipMemcpyHostToDevice);
+  af::GateArgs g{};
+  g.in = d_in; g.out = d_in; g.gain_trace = d_trace; g.chatter = d_chatter; g.state = nullptr;
+  g.threshold_db = threshold_db;
+  g.attack_coeff = af::time_constant_to_coeff(attack_ms, sample_rate);    // gate.rs:160-162
+  g.release_coeff = af::time_constant_to_coeff(release_ms, sample_rate);
+  g.rms_coeff = af::time_constant_to_coeff(8.0, sample_rate);
+  g.n_samples = n_samples; g.stride = n_samples; g.n_streams = n_streams; g.block = trace_block; g.vad_mode = vad_mode ? 1 : 0;
+  g.hold_samples = (int32_t)std::llround(sample_rate * 50.0 / 1000.0);
+  g.window_samples = (int32_t)std::llround(sample_rate * 500.0 / 1000.0);
+  g.cooldown_samples = (int32_t)std::llround(sample_rate * 1000.0 / 1000.0);
+  g.relax_samples = (int32_t)std::llround(sample_rate * 700.0 / 1000.0);
+  if (err == hipSuccess) err = af::launch_gate(g, nullptr);
+  if (err == hipSuccess && n_samples > 0)
+    err = hipMemcpy2D(out, sizeof(float) * stream_stride, d_in, sizeof(float) * n_samples, sizeof(float) * n_samples, n_streams,
+                      hipMemcpyDeviceToHost);
+  if (err == hipSuccess && gain_trace && blocks > 0)
+    err = hipMemcpy(gain_trace, d_trace, sizeof(float) * blocks * n_streams, hipMemcpyDeviceToHost);
+  if (err == hipSuccess && chatter_events) err = hipMemcpy(chatter_events, d_chatter, sizeof(uint64_t) * n_streams, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in);
+  (void)hipFree(d_trace);
+  (void)hipFree(d_chatter);
+  if (err != hipSuccess) return fail(AF_ERR_BACKEND, "gate failed: %s", hipGetErrorString(err));
+  return AF_OK;
+}
+
+}  // extern "C"

@@ -140,6 +140,7 @@ SIGNATURES = {
     "af_resampler_process_device": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "af_resampler_process_host": (C.c_int, [_vp, _dp, _dp, _i64, _i32, _i64, _i64]),
     "af_resampler_last_kernel_ms": (C.c_int, [_vp, _dp]),
+    "af_gate_process_host": (C.c_int, [_fp, _fp, _i64, _i32, _i64, _d, _d, _d, _d, _i32, _i32, _fp, C.POINTER(C.c_uint64), _i32]),
     "af_measure_integrated_loudness_device": (C.c_int, [_vp, _i64, _i32, _i64, C.c_uint32, _i32, _dp, C.POINTER(_i32)]),
     "af_measure_integrated_loudness_host": (C.c_int, [_fp, _i64, _i32, _i64, C.c_uint32, _i32, _dp, C.POINTER(_i32)]),
     "af_eq_magnitude_response": (C.c_int, [_dp, _sz, _dp, _d, _dp]),

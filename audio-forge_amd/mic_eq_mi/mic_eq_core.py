@@ -793,3 +793,63 @@ def measure_integrated_loudness(audio, sample_rate: int) -> float:
     if status[0] != 0:
         raise ValueError("Loudness measurement failed: audio did not produce a finite gated loudness")
     return float(lufs[0])
+
+
+# ------------------------------------------------------------------ noise gate + suppressor order
+RNNOISE_FRAME = 480  # dsp/rnnoise.rs:3
+
+
+def gate_batch(audio: np.ndarray, threshold_db: float = -40.0, attack_ms: float = 10.0, release_ms: float = 100.0,
+               sample_rate: float = 48_000.0, vad_mode: bool = True, trace_block: int = RNNOISE_FRAME, device: int = 0):
+    """NoiseGate expander path (gate.rs:626-637) over [n_streams, n]: (output, gain trace [blocks, n_streams], chatter events)."""
+    a = np.ascontiguousarray(audio, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("audio must be [n_streams, n]")
+    n_streams, n = a.shape
+    out = np.empty_like(a)
+    blocks = -(-n // trace_block)
+    trace = np.zeros((blocks, n_streams), dtype=np.float32)
+    chatter = np.zeros(n_streams, dtype=np.uint64)
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.load().af_gate_process_host(a.ctypes.data_as(fp), out.ctypes.data_as(fp), n, n_streams, n, float(threshold_db),
+                                                float(attack_ms), float(release_ms), float(sample_rate), int(bool(vad_mode)),
+                                                int(trace_block), trace.ctypes.data_as(fp),
+                                                chatter.ctypes.data_as(C.POINTER(C.c_uint64)), int(device)))
+    return out, trace, chatter
+
+
+def simulate_gate_suppressor_order(audio, vad_probabilities: Sequence[float], suppressor_before_gate: bool,
+                                   suppressor_strength: float = 1.0, settings: Mapping[str, object] | None = None) -> dict[str, Any]:
+    """python_api.rs:288-376: gate (VadAssisted, no VadAutoGate attached) and RNNoise in either order, 480-sample frames."""
+    import time
+
+    strength = float(suppressor_strength)
+    if not np.isfinite(strength) or not 0.0 <= strength <= 1.0:
+        raise ValueError("suppressor_strength must be finite and between 0 and 1")
+    x = _audio_1d(audio)
+    n = x.size
+    frames = -(-n // RNNOISE_FRAME)
+    probs = np.asarray(list(vad_probabilities), dtype=np.float64)
+    if probs.size != frames or not np.all(np.isfinite(probs)) or np.any(probs < 0.0) or np.any(probs > 1.0):
+        raise ValueError(f"expected {frames} finite VAD probabilities at the 10 ms RNNoise cadence")
+    started = time.perf_counter()
+    padded = np.zeros((1, frames * RNNOISE_FRAME), dtype=np.float32)
+    padded[0, :n] = x
+    gate_args = (_get(settings, "gate_threshold_db", -40.0), _get(settings, "gate_attack_ms", 10.0),
+                 _get(settings, "gate_release_ms", 100.0), 48_000.0, True, RNNOISE_FRAME)
+    if frames == 0:
+        out, trace, chatter = padded, np.zeros((0, 1), np.float32), np.zeros(1, np.uint64)
+    elif suppressor_before_gate:
+        out, trace, chatter = gate_batch(suppress(padded, strength), *gate_args)
+    else:
+        gated, trace, chatter = gate_batch(padded, *gate_args)
+        out = suppress(gated, strength)
+    return {
+        "output_audio": out[0, :n].tolist(),
+        "gate_gain": [float(v) for v in trace[:, 0]],
+        "gate_chatter_event_count": int(chatter[0]),
+        "gate_noise_floor_db": -60.0,            # NoiseGate::noise_floor() without a VadAutoGate, gate.rs:929-934
+        "gate_noise_floor_reliability": 0.0,     # gate.rs:938-943
+        "suppressor_latency_samples": RNNOISE_FRAME,  # rnnoise.rs:313-315
+        "runtime_ms": (time.perf_counter() - started) * 1000.0,
+    }

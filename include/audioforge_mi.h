@@ -261,6 +261,18 @@ int af_resampler_process_host(af_resampler *r, const double *in, double *out, in
 /* HIP-event time of the last launch */
 int af_resampler_last_kernel_ms(af_resampler *r, double *ms);
 
+/* ---- noise gate -------------------------------------------------------------------------------
+ * NoiseGate (rust-core/src/dsp/gate.rs) on the path `simulate_gate_suppressor_order` exercises
+ * (python_api.rs:312-319 builds the gate without a VadAutoGate, so process_block_inplace runs the per-sample
+ * downward expander, gate.rs:626-637).  One-shot over whole clips from the initial state (gate.rs:158-225);
+ * `vad_mode` != 0 = GateMode::VadAssisted/VadOnly (arms the chatter auto-relax, gate.rs:598-601).
+ * gain_trace: [ceil(n / trace_block)][n_streams] `current_gain()` at the end of every block (python_api.rs:356);
+ * chatter_events: [n_streams] `chatter_event_count()`.  Either may be null. */
+int af_gate_process_host(const float *in, float *out, int64_t n_samples, int32_t n_streams, int64_t stream_stride,
+                         double threshold_db, double attack_ms, double release_ms, double sample_rate,
+                         int32_t vad_mode, int32_t trace_block, float *gain_trace, uint64_t *chatter_events,
+                         int32_t device);
+
 /* ---- integrated loudness ------------------------------------------------------------------
  * measure_integrated_loudness (rust-core/src/lib.rs:290-298 over dsp/loudness.rs:43-83): BS.1770 gated loudness of
  * whole clips, ebur128 `Mode::I | Mode::HISTOGRAM`, mono.  One value per stream; `status` (optional, [n_streams])

@@ -2216,3 +2216,89 @@ int afo_measure_integrated_loudness(const float *audio, size_t n, uint32_t sampl
   afo_loudness_free(&m);
   return rc;
 }
+
+
+/* ------------------------------------------------------------------ noise gate (dsp/gate.rs) */
+#define GATE_EXPANDER_RATIO 4.0
+#define GATE_EXPANDER_RANGE_DB 36.0
+#define GATE_AUTO_RELAX_RANGE_DB 24.0
+#define GATE_HYSTERESIS_DB 4.0
+/* gate.rs:158-225 */
+void afo_gate_init(afo_gate *g, double threshold_db, double attack_ms, double release_ms, double sample_rate) {
+  memset(g, 0, sizeof(*g));
+  g->threshold_db = threshold_db;
+  g->attack_coeff = afo_time_constant_to_coeff(attack_ms, sample_rate);
+  g->release_coeff = afo_time_constant_to_coeff(release_ms, sample_rate);
+  g->rms_coeff = afo_time_constant_to_coeff(8.0, sample_rate);
+  g->detector_level_db = -120.0;
+  g->sample_rate = sample_rate;
+  g->enabled = 1;
+}
+/* gate.rs:812-821 */
+void afo_gate_set_vad_mode(afo_gate *g, int vad_mode) {
+  g->vad_mode = vad_mode;
+  if (!vad_mode) g->auto_relax_remaining_samples = 0;
+}
+/* gate.rs:562-575 */
+static void gate_advance_chatter_timers(afo_gate *g) {
+  if (g->auto_relax_remaining_samples > 0) g->auto_relax_remaining_samples -= 1;
+  if (g->chatter_window_remaining_samples > 0) {
+    g->chatter_window_remaining_samples -= 1;
+    if (g->chatter_window_remaining_samples == 0) g->chatter_transition_count = 0;
+  }
+  if (g->chatter_cooldown_samples > 0) g->chatter_cooldown_samples -= 1;
+}
+/* gate.rs:578-611 */
+static void gate_track_transition(afo_gate *g, int effective_open) {
+  if (!g->has_effective_gate_state) {
+    g->effective_gate_open = effective_open;
+    g->has_effective_gate_state = 1;
+    gate_advance_chatter_timers(g);
+    return;
+  }
+  if (effective_open != g->effective_gate_open) {
+    g->effective_gate_open = effective_open;
+    if (g->chatter_window_remaining_samples == 0) {
+      g->chatter_window_remaining_samples = (size_t)round(g->sample_rate * 500.0 / 1000.0);
+      g->chatter_transition_count = 1;
+    } else {
+      g->chatter_transition_count += 1;
+    }
+    if (g->chatter_transition_count >= 4 && g->chatter_cooldown_samples == 0) {
+      g->chatter_event_count += 1;
+      g->chatter_cooldown_samples = (size_t)round(g->sample_rate * 1000.0 / 1000.0);
+      if (g->vad_mode) g->auto_relax_remaining_samples = (size_t)round(g->sample_rate * 700.0 / 1000.0);
+      g->chatter_window_remaining_samples = 0;
+      g->chatter_transition_count = 0;
+    }
+  }
+  gate_advance_chatter_timers(g);
+}
+/* gate.rs:626-637 over update_detector (265-285), detector_gain_reduction_db (298-306), apply_gain (613-623) */
+float afo_gate_process_sample(afo_gate *g, float input) {
+  if (!g->enabled) return input;
+  const double x = (double)input;
+  g->rms_envelope_sq = g->rms_coeff * g->rms_envelope_sq + (1.0 - g->rms_coeff) * x * x;
+  g->detector_level_db = afo_linear_to_db(sqrt(g->rms_envelope_sq), 1e-10);
+  if (g->detector_level_db >= g->threshold_db) {
+    g->is_open = 1;
+    g->hold_remaining_samples = (size_t)round(g->sample_rate * 50.0 / 1000.0);
+  } else if (g->hold_remaining_samples > 0) {
+    g->hold_remaining_samples -= 1;
+    g->is_open = 1;
+  } else if (g->detector_level_db <= g->threshold_db - GATE_HYSTERESIS_DB) {
+    g->is_open = 0;
+  }
+  const double range = g->auto_relax_remaining_samples > 0 ? GATE_AUTO_RELAX_RANGE_DB : GATE_EXPANDER_RANGE_DB;
+  const double gr = g->is_open ? 0.0
+                               : clampd((g->threshold_db - g->detector_level_db) * (1.0 - 1.0 / GATE_EXPANDER_RATIO), 0.0, range);
+  gate_track_transition(g, g->is_open);
+  const double target_gain = afo_db_to_linear(-gr);
+  const double coeff = target_gain > g->current_gain ? g->attack_coeff : g->release_coeff;
+  g->current_gain = coeff * g->current_gain + (1.0 - coeff) * target_gain;
+  return (float)(x * g->current_gain);
+}
+void afo_gate_process_block(afo_gate *g, float *buf, size_t n) {
+  if (!g->enabled) return;
+  for (size_t i = 0; i < n; ++i) buf[i] = afo_gate_process_sample(g, buf[i]);
+}

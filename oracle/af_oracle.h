@@ -410,6 +410,25 @@ double afo_linear_to_db(double linear, double min_linear);
 void afo_kat_signal(float *out, size_t n_blocks, uint64_t noise_state0, double fundamental_hz,
                     double phrase_hz);
 
+
+/* ---- noise gate (dsp/gate.rs): the downward-expander path that runs when no VadAutoGate is attached, which is
+ * what simulate_gate_suppressor_order builds (python_api.rs:312-319: NoiseGate::new + set_gate_mode only).
+ * `vad_mode` != 0 (VadAssisted / VadOnly) arms the chatter auto-relax (gate.rs:598-601). ---- */
+typedef struct afo_gate {
+  double threshold_db, attack_coeff, release_coeff, rms_coeff, sample_rate;
+  double rms_envelope_sq, detector_level_db, current_gain;
+  size_t hold_remaining_samples;
+  int is_open, enabled, vad_mode;
+  int effective_gate_open, has_effective_gate_state;
+  size_t chatter_window_remaining_samples, chatter_cooldown_samples, auto_relax_remaining_samples;
+  uint32_t chatter_transition_count;
+  uint64_t chatter_event_count;
+} afo_gate;
+void afo_gate_init(afo_gate *g, double threshold_db, double attack_ms, double release_ms, double sample_rate);
+void afo_gate_set_vad_mode(afo_gate *g, int vad_mode);
+float afo_gate_process_sample(afo_gate *g, float input);
+void afo_gate_process_block(afo_gate *g, float *buf, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

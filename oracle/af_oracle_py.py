@@ -449,3 +449,70 @@ def resampler_calculate_cutoff(sinc_len: int = 128, window: str = "blackman") ->
     L.afo_resampler_calculate_cutoff.restype = C.c_float
     L.afo_resampler_calculate_cutoff.argtypes = [C.c_size_t, C.c_int]
     return float(L.afo_resampler_calculate_cutoff(int(sinc_len), RESAMPLER_WINDOWS[window]))
+
+
+class Gate:
+    """dsp/gate.rs NoiseGate without a VadAutoGate attached (the expander path)."""
+
+    class _State(C.Structure):
+        _fields_ = [("threshold_db", C.c_double), ("attack_coeff", C.c_double), ("release_coeff", C.c_double),
+                    ("rms_coeff", C.c_double), ("sample_rate", C.c_double), ("rms_envelope_sq", C.c_double),
+                    ("detector_level_db", C.c_double), ("current_gain", C.c_double), ("hold_remaining_samples", C.c_size_t),
+                    ("is_open", C.c_int), ("enabled", C.c_int), ("vad_mode", C.c_int), ("effective_gate_open", C.c_int),
+                    ("has_effective_gate_state", C.c_int), ("chatter_window_remaining_samples", C.c_size_t),
+                    ("chatter_cooldown_samples", C.c_size_t), ("auto_relax_remaining_samples", C.c_size_t),
+                    ("chatter_transition_count", C.c_uint32), ("chatter_event_count", C.c_uint64)]
+
+    def __init__(self, threshold_db=-40.0, attack_ms=10.0, release_ms=100.0, sample_rate=48_000.0, vad_mode=False):
+        L = lib()
+        L.afo_gate_init.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.afo_gate_set_vad_mode.argtypes = [C.c_void_p, C.c_int]
+        L.afo_gate_process_block.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
+        self.s = Gate._State()
+        L.afo_gate_init(C.byref(self.s), threshold_db, attack_ms, release_ms, sample_rate)
+        L.afo_gate_set_vad_mode(C.byref(self.s), int(vad_mode))
+
+    def process(self, audio: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(audio, dtype=np.float32).copy()
+        lib().afo_gate_process_block(C.byref(self.s), _fptr(out), out.size)
+        return out
+
+    @property
+    def current_gain(self) -> float:
+        return float(np.float32(self.s.current_gain))
+
+    @property
+    def is_open(self) -> bool:
+        return bool(self.s.is_open)
+
+    @property
+    def chatter_event_count(self) -> int:
+        return int(self.s.chatter_event_count)
+
+
+def simulate_gate_suppressor_order(audio, vad_probabilities, suppressor_before_gate: bool, suppressor_strength: float = 1.0,
+                                   settings: dict | None = None, weight_seed: int = 0x5EED) -> dict:
+    """python_api.rs:288-376 over the restatements (480-sample frames, last one zero padded)."""
+    settings = settings or {}
+    x = np.ascontiguousarray(audio, dtype=np.float32)
+    n = x.size
+    frames = -(-n // 480)
+    padded = np.zeros(frames * 480, dtype=np.float32)
+    padded[:n] = x
+    gate = Gate(settings.get("gate_threshold_db", -40.0), settings.get("gate_attack_ms", 10.0),
+                settings.get("gate_release_ms", 100.0), 48_000.0, vad_mode=True)
+    gains = []
+
+    def run_gate(sig):
+        out = np.empty_like(sig)
+        for f in range(frames):
+            out[f * 480 : (f + 1) * 480] = gate.process(sig[f * 480 : (f + 1) * 480])
+            gains.append(gate.current_gain)
+        return out
+
+    if suppressor_before_gate:
+        y = run_gate(suppressor_process(padded, suppressor_strength, weight_seed))
+    else:
+        y = suppressor_process(run_gate(padded), suppressor_strength, weight_seed)
+    return {"output_audio": y[:n], "gate_gain": gains, "gate_chatter_event_count": gate.chatter_event_count,
+            "gate_noise_floor_db": -60.0, "gate_noise_floor_reliability": 0.0, "suppressor_latency_samples": 480}

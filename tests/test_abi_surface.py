@@ -43,9 +43,18 @@ def test_package_imports_under_its_hyphenated_name():
     assert callable(pkg.simulate_auto_eq_chain)
 
 
-def test_missing_operator_raises_import_error(mi):
+def test_operator_table_is_complete_and_missing_core_raises_import_error(mi):
+    """python/mic_eq/__init__.py:38-73: every offline operator name the reference re-exports resolves to a
+    built function; the degradation path for an absent one is the reference's own `_missing_core` (ImportError)."""
+    for name in ("simulate_auto_eq_chain", "simulate_auto_makeup_control", "simulate_gate_suppressor_order",
+                 "simulate_eq_v2", "simulate_product_resampler", "product_resampler_configuration",
+                 "eq_magnitude_response", "eq_magnitude_response_v2", "measure_integrated_loudness"):
+        fn = getattr(mi, name)
+        assert callable(fn) and fn is not mi._missing_core, name
     with pytest.raises(ImportError):
-        mi.simulate_gate_suppressor_order(np.zeros(4, dtype=np.float32), [0.0], True)
+        mi._missing_core(np.zeros(4, dtype=np.float32))
+    with pytest.raises(ValueError):  # argument contract is checked before any GPU work (python_api.rs:296-311)
+        mi.simulate_gate_suppressor_order(np.zeros(4, dtype=np.float32), [0.0, 0.0], True)
 
 
 def test_eq_response_matches_oracle_bit_for_bit(mi, oracle):

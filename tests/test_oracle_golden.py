@@ -337,3 +337,30 @@ def test_integrated_loudness_reference_properties(oracle):
             oracle.measure_integrated_loudness(bad, 48_000)
     with pytest.raises(ValueError):
         oracle.measure_integrated_loudness(np.array([0.1], np.float32), 12_345)
+
+
+def test_gate_reference_properties(oracle):
+    """gate.rs:958-1070 on the oracle's expander path."""
+    g = oracle.Gate(-40.0, 10.0, 100.0)
+    g.process(np.full(3_000, 0.1, np.float32))
+    open_gain = g.current_gain
+    assert open_gain > 0.8
+    g.process(np.full(10_000, 0.0001, np.float32))
+    assert g.current_gain < open_gain * 0.7 and g.current_gain < 0.5
+    g = oracle.Gate(-40.0, 1.0, 1.0)
+    g.process(np.zeros(4_000, np.float32))
+    assert abs(g.current_gain - 10.0 ** (-36.0 / 20.0)) < 0.02
+    g = oracle.Gate(-40.0, 1.0, 20.0)
+    g.process(np.full(1, 0.1, np.float32))
+    assert not g.is_open                                   # 8 ms RMS detector rejects a click
+    g.process(np.full(2_000, 0.1, np.float32))
+    assert g.is_open
+    g.process(np.zeros(1_000, np.float32))
+    assert g.is_open                                       # 50 ms hold
+    g.process(np.zeros(4_000, np.float32))
+    assert not g.is_open
+    g = oracle.Gate(-40.0, 1.0, 10.0)
+    for _ in range(5):
+        g.process(np.full(2_000, 0.1, np.float32))
+        g.process(np.zeros(4_500, np.float32))
+    assert g.chatter_event_count > 0
