@@ -403,7 +403,7 @@ struct SpectrumLds {
 
 // Frames handled by one wave of the frame-parallel kernels: the per-wave setup (twiddles, tables) is
 // a dozen dependent global loads, comparable to one transform, so it is shared by kFramesPerWave frames.
-constexpr int kFramesPerWave = 1;  // measured: 1 is fastest (the kernels are latency bound; more, shorter waves win)
+constexpr int kFramesPerWave = 10;  // measured with the butterfly transform: 1 -> 357 ms per bench step, 5 -> 338, 10 -> 336
 
 extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArgs a, SuppTables tb) {
   __shared__ SpectrumLds L;
