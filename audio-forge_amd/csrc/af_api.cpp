@@ -30,7 +30,7 @@ hipError_t launch_merge_side_stats(BlockStats *rows, const BlockStats *input_row
                                    int64_t n, hipStream_t stream);
 hipError_t launch_resample(const double *in, double *out, const ResamplePos *pos, const double *table, int64_t n_in,
                            int64_t n_out, int64_t in_stride, int64_t out_stride, int32_t n_streams, int32_t sinc_len,
-                           double ratio, hipStream_t stream);
+                           double ratio, int variant, hipStream_t stream);
 int resample_segment_outputs(double ratio, int sinc_len);
 hipError_t launch_kweight_energy(const float *audio, double *partial, int32_t *non_finite, const double b[5],
                                  const double a5[5], int64_t n_samples, int64_t stride, int64_t n100, int32_t n_streams,
@@ -1033,6 +1033,7 @@ struct af_resampler {
   int64_t in_capacity = 0, out_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  int variant = 0;  // 0: matrix-core kernel when the shape allows, 1: vector kernel (AF_RESAMPLER_VARIANT=valu)
 };
 
 namespace {
@@ -1094,6 +1095,7 @@ int af_resampler_create(uint32_t input_rate, uint32_t output_rate, int64_t chunk
   af_resampler *r = new af_resampler();
   r->device = device;
   r->plan.build(input_rate, output_rate, chunk_size, sinc_len, window);
+  if (const char *env = std::getenv("AF_RESAMPLER_VARIANT")) r->variant = std::strcmp(env, "valu") == 0 ? 1 : 0;
   *out = r;
   return AF_OK;
 }
@@ -1151,7 +1153,7 @@ int af_resampler_process_device(af_resampler *r, const double *d_in, double *d_o
   }
   AF_HIP(hipEventRecord(r->ev0, s));
   AF_HIP(af::launch_resample(d_in, d_out, r->d_pos, r->d_table, n_in, r->planned_n_out, in_stride, out_stride, n_streams,
-                             r->plan.sinc_len, r->plan.ratio, s));
+                             r->plan.sinc_len, r->plan.ratio, r->variant, s));
   AF_HIP(hipEventRecord(r->ev1, s));
   r->timed = true;
   return AF_OK;

@@ -16,7 +16,7 @@
 namespace af {
 
 constexpr int kResampleOversampling = 256;
-constexpr int kResampleTablePad = 2;  // zero taps either side of every sinc row (see af_resampler.hip)
+constexpr int kResampleTablePad = 16;  // zero taps either side of every sinc row (see af_resampler.hip)
 
 enum ResampleWindow : int { kWinBlackmanHarris = 0, kWinBlackmanHarris2, kWinBlackman, kWinBlackman2, kWinHann, kWinHann2 };
 
