@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime under the same soname as /opt/rocm's: whichever loads first serves the
+    import torch  # noqa: F401  whole process, and torch refuses to start on the other one -- so let torch go first
+except ImportError:  # pragma: no cover
+    torch = None
+
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 for p in (ROOT, ROOT / "oracle", ROOT / "audio-forge_amd", ROOT / "tests"):
     if str(p) not in sys.path:
