@@ -10,7 +10,10 @@ import ctypes as C
 import pathlib
 
 PKG_DIR = pathlib.Path(__file__).resolve().parents[1]
-LIB_PATH = PKG_DIR / "libaudioforge_mi.so"
+import os
+
+# AF_LIB_PATH: load another build of the same library (same-box A/B runs of kernel variants)
+LIB_PATH = pathlib.Path(os.environ.get("AF_LIB_PATH") or (PKG_DIR / "libaudioforge_mi.so"))
 
 AF_OK = 0
 AF_ERR_INVALID_ARGUMENT = -1
