@@ -13,9 +13,11 @@
  *   KAT-pinned    : biquad, EQ, de-esser, compressor, limiter, true-peak limiter /
  *                   detector, offline block processor (tests.rs:1784-1885 and the
  *                   tracked evaluation reports).
- *   spec-restated : K-weighted momentary loudness (ebur128 0.1.10 is not vendored),
- *                   product resampler (rubato 0.14.1), RNNoise core (nnnoiseless
- *                   0.5.2) -- parity unpinned for those three.
+ *   measurement-pinned : product resampler (rubato 0.14.1 is not vendored; af_resampler.c
+ *                   reproduces the reference's published 16-digit measurements of it).
+ *   spec-restated : K-weighted momentary / integrated loudness (ebur128 0.1.10 is not
+ *                   vendored), RNNoise core (nnnoiseless 0.5.2, af_rnnoise.c), noise gate
+ *                   expander path (behavioural pins only) -- parity unpinned for those.
  */
 #ifndef AF_ORACLE_H
 #define AF_ORACLE_H
