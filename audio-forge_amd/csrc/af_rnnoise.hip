@@ -555,14 +555,30 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
     {
       // coarse: 4x decimated, 147 lags x 240 products (lane per lag, left-to-right order)
       const int len = kRnnWindow >> 2, mp = max_pitch >> 2;
-      for (int lag = lane; lag < mp; lag += 64) {
-        float sum = 0.0f;
+      {
+        // the three lag rounds (lane, lane + 64, lane + 128) share every x-value: one loop, three running sums
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        const float *y = L.ds + 2 * lane;
+        const bool third = lane + 128 < mp;  // lags >= mp are never stored; keep their reads inside ds
+        const float *y2 = third ? y + 256 : y;
 #pragma unroll 8
-        for (int j = 0; j < len; ++j) sum += x_lp[2 * j] * L.ds[2 * (j + lag)];
-        const float x16 = sum * 1e-12f;
-        L.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
-        const float ya = L.ds[2 * (lag + len)], yb = L.ds[2 * lag];
-        L.da[lag] = ya * ya - yb * yb;
+        for (int j = 0; j < len; ++j) {
+          const float xs = x_lp[2 * j];
+          s0 += xs * y[2 * j];
+          s1 += xs * y[2 * j + 128];
+          s2 += xs * y2[2 * j];
+        }
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+          const int lag = lane + 64 * round;
+          if (lag < mp) {
+            const float sum = round == 0 ? s0 : (round == 1 ? s1 : s2);
+            const float x16 = sum * 1e-12f;
+            L.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
+            const float ya = L.ds[2 * (lag + len)], yb = L.ds[2 * lag];
+            L.da[lag] = ya * ya - yb * yb;
+          }
+        }
       }
       const float Syy0 = 1.0f + wave_dot64_sq_stride2(L.ds, len, lane);
       __syncthreads();
