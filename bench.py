@@ -276,7 +276,7 @@ def main() -> None:
                        "max_compressor_gr_db": merged["compressor_gain_reduction_db"],
                        "true_peak_limited_blocks": int(merged["true_peak_limited_events"])},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run artefact (rank 0, N = 1)
             line["cpu_baseline"] = cpu_baseline(args.seconds, full)
         print(json.dumps(line))
     engine.close()
