@@ -278,6 +278,8 @@ def main() -> None:
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run artefact (rank 0, N = 1)
             line["cpu_baseline"] = cpu_baseline(args.seconds, full)
+        elif world > 1:
+            line["cpu_baseline"] = None
         print(json.dumps(line))
     engine.close()
     if distributed:
