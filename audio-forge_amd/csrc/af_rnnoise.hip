@@ -194,8 +194,7 @@ __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
 // 960 = 15 x 64.  Lane n2 transforms x[64 n1 + n2] over n1 in registers as a 3 x 5 prime-factor DFT (no
 // twiddles between the two), applies W_960^(n2 k1), and the fifteen 64-point transforms across lanes run as
 // two passes of radix-8 butterflies through LDS (120 butterflies per pass, two per lane).
-// out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.  `a` is consumed (and reused as scratch, so it must
-// hold kFftBuf elements); the result lands in `b`.
+// out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.
 constexpr int kFftBuf = 15 * 72;  // fifteen 8 x 8 tiles with 9-element rows: conflict-free in both passes
 
 __device__ __forceinline__ float2 cmul(float2 x, float2 w) { return make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x); }
@@ -261,7 +260,10 @@ __device__ __forceinline__ void dft8(const float2 *v, float2 *V) {
   V[7] = csub(b3, w3);
 }
 
-__device__ __forceinline__ void fft960_wave(float2 *a, float2 *b, const FftLane &fl, int lane, float scale) {
+// In place: every pass reads its operands into registers, crosses a barrier, then writes over the same buffer
+// (which must hold kFftBuf elements) -- one 8.6 KB buffer per wave instead of two, i.e. half again as many
+// waves per CU for kernels whose occupancy is capped by LDS.  The result lands in a[0 .. 960).
+__device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int lane, float scale) {
   float2 x[15];
 #pragma unroll
   for (int n1 = 0; n1 < 15; ++n1) x[n1] = a[64 * n1 + lane];
@@ -279,39 +281,56 @@ __device__ __forceinline__ void fft960_wave(float2 *a, float2 *b, const FftLane 
 #pragma unroll
       for (int kb = 0; kb < 5; ++kb) {
         const int k1 = (10 * ka + 6 * kb) % 15;
-        b[k1 * 64 + lane] = cmul(y[kb], fl.tw960[k1]);
+        a[k1 * 64 + lane] = cmul(y[kb], fl.tw960[k1]);
       }
     }
   }
   __syncthreads();
   // 64 = 8 x 8, n2 = 8 p + q, k2 = r + 8 t.  Pass A: cell (k1, q): 8-point DFT over p, times W_64^(q r).
+  {
+    float2 v0[8], v1[8];
+    const int id1 = lane + 64;
+    const int k1a = lane >> 3, q = lane & 7, k1b = id1 >> 3;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int id = lane + 64 * half;
-    if (id < 120) {
-      const int k1 = id >> 3, q = id & 7;
-      float2 v[8], V[8];
+    for (int pp = 0; pp < 8; ++pp) v0[pp] = a[k1a * 64 + 8 * pp + q];
+    if (id1 < 120) {
 #pragma unroll
-      for (int pp = 0; pp < 8; ++pp) v[pp] = b[k1 * 64 + 8 * pp + q];
-      dft8(v, V);
-      a[k1 * 72 + q] = V[0];
+      for (int pp = 0; pp < 8; ++pp) v1[pp] = a[k1b * 64 + 8 * pp + q];
+    }
+    __syncthreads();
+    float2 V[8];
+    dft8(v0, V);
+    a[k1a * 72 + q] = V[0];
 #pragma unroll
-      for (int r = 1; r < 8; ++r) a[k1 * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
+    for (int r = 1; r < 8; ++r) a[k1a * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
+    if (id1 < 120) {
+      dft8(v1, V);
+      a[k1b * 72 + q] = V[0];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) a[k1b * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
     }
   }
   __syncthreads();
   // Pass B: cell (k1, r): 8-point DFT over q; output bin k1 + 15 (r + 8 t).
+  {
+    float2 v0[8], v1[8];
+    const int id1 = lane + 64;
+    const int k1a = lane >> 3, r = lane & 7, k1b = id1 >> 3;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int id = lane + 64 * half;
-    if (id < 120) {
-      const int k1 = id >> 3, r = id & 7;
-      float2 v[8], V[8];
+    for (int q = 0; q < 8; ++q) v0[q] = a[k1a * 72 + r * 9 + q];
+    if (id1 < 120) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = a[k1 * 72 + r * 9 + q];
-      dft8(v, V);
+      for (int q = 0; q < 8; ++q) v1[q] = a[k1b * 72 + r * 9 + q];
+    }
+    __syncthreads();
+    float2 V[8];
+    dft8(v0, V);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) b[k1 + 15 * (r + 8 * t)] = make_float2(V[t].x * scale, V[t].y * scale);
+    for (int t = 0; t < 8; ++t) a[k1a + 15 * (r + 8 * t)] = make_float2(V[t].x * scale, V[t].y * scale);
+    if (id1 < 120) {
+      dft8(v1, V);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[k1b + 15 * (r + 8 * t)] = make_float2(V[t].x * scale, V[t].y * scale);
     }
   }
   __syncthreads();
@@ -396,7 +415,7 @@ __device__ __forceinline__ float interp_gain(const float *bandE, const float *fr
 // ============================================================================== analysis, part 1
 // One wave per (frame, stream): window, forward transform, band energies.  Fully parallel.
 struct SpectrumLds {
-  float2 fa[kFftBuf], fb[kRnnWindow];
+  float2 fa[kFftBuf];
   float frac[404];
   float bandtmp[128];
 };
@@ -426,10 +445,10 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArg
 #pragma unroll
     for (int j = 0; j < 15; ++j) L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow + lane + 64 * j] * win[j], 0.0f);
     __syncthreads();
-    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+    fft960_wave(L.fa, fl, lane, 1.0f / kRnnWindow);
     float2 *Xg = a.X + cell * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fb[i];
-    const float ex = band_accumulate_wave(L.fb, L.fb, L.frac, lane, L.bandtmp);
+    for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fa[i];
+    const float ex = band_accumulate_wave(L.fa, L.fa, L.frac, lane, L.bandtmp);
     if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
   }
 }
@@ -824,7 +843,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a
 // ============================================================================== analysis, part 3
 // One wave per (frame, stream): pitch-aligned transform, band energy / correlation, their cepstral features.
 struct PitchSpecLds {
-  float2 fa[kFftBuf], fb[kRnnWindow];
+  float2 fa[kFftBuf];
   float2 X[kRnnFreq + 3];
   float frac[404];
   float Exp[kRnnBands];
@@ -861,11 +880,11 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppAr
     for (int j = 0; j < 15; ++j)
       L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + lane + 64 * j] * win[j], 0.0f);
     __syncthreads();
-    fft960_wave(L.fa, L.fb, fl, lane, 1.0f / kRnnWindow);
+    fft960_wave(L.fa, fl, lane, 1.0f / kRnnWindow);
     float2 *Pg = a.P + cell * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fb[i];
-    const float ep = band_accumulate_wave(L.fb, L.fb, L.frac, lane, L.bandtmp);
-    float exp_ = band_accumulate_wave(L.X, L.fb, L.frac, lane, L.bandtmp);
+    for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fa[i];
+    const float ep = band_accumulate_wave(L.fa, L.fa, L.frac, lane, L.bandtmp);
+    float exp_ = band_accumulate_wave(L.X, L.fa, L.frac, lane, L.bandtmp);
     if (lane < kRnnBands) {
       const float ex = rec->Ex[lane];
       exp_ = exp_ / sqrtf(.001f + ex * ep);
@@ -1120,7 +1139,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
 struct SynthLds {
   float frac[404];
   int32_t band_of[484];
-  float2 fa[kFftBuf], fb[kRnnWindow];
+  float2 fa[kFftBuf];
   float2 X[kRnnFreq + 3], P[kRnnFreq + 3];
   float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], g[kRnnBands], graw[kRnnBands], r[kRnnBands], norm[kRnnBands];
   float bandtmp[128];
@@ -1200,12 +1219,12 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs
     for (int i = lane; i < kRnnWindow; i += 64)
       L.fa[i] = i < kRnnFreq ? L.X[i] : make_float2(L.X[kRnnWindow - i].x, -L.X[kRnnWindow - i].y);
     __syncthreads();
-    fft960_wave(L.fa, L.fb, fl, lane, 1.0f);
+    fft960_wave(L.fa, fl, lane, 1.0f);
     float *y = reinterpret_cast<float *>(Pg);
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
       const int i = lane + 64 * j;
-      y[i] = L.fb[(kRnnWindow - i) % kRnnWindow].x * win[j];
+      y[i] = L.fa[(kRnnWindow - i) % kRnnWindow].x * win[j];
     }
   }
 }
