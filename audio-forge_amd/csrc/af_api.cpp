@@ -1033,7 +1033,7 @@ struct af_resampler {
   int64_t in_capacity = 0, out_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
-  int variant = 0;  // 0: matrix-core kernel when the shape allows, 1: vector kernel (AF_RESAMPLER_VARIANT=valu)
+  int variant = 0;  // 0: matrix-core kernel (64 streams per workgroup) when the shape allows; AF_RESAMPLER_VARIANT=valu -> 1: vector kernel, =mfma32 -> 2: matrix-core kernel with 32 streams per workgroup
 };
 
 namespace {
@@ -1095,7 +1095,7 @@ int af_resampler_create(uint32_t input_rate, uint32_t output_rate, int64_t chunk
   af_resampler *r = new af_resampler();
   r->device = device;
   r->plan.build(input_rate, output_rate, chunk_size, sinc_len, window);
-  if (const char *env = std::getenv("AF_RESAMPLER_VARIANT")) r->variant = std::strcmp(env, "valu") == 0 ? 1 : 0;
+  if (const char *env = std::getenv("AF_RESAMPLER_VARIANT")) r->variant = std::strcmp(env, "valu") == 0 ? 1 : (std::strcmp(env, "mfma32") == 0 ? 2 : 0);
   *out = r;
   return AF_OK;
 }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kWaves *kResLanes) void resample_kernel(ResampleArg
 // coefficients ONE per-lane 8-byte load per 4096 FMAs (all four stream groups reuse it) and can be fetched far
 // ahead, so neither the LDS pipe nor the scalar cache sits next to the arithmetic any more.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-constexpr int kMfWaves = 16, kMfSeg = 128, kMfRows = 288;
+constexpr int kMfSeg = 128, kMfRows = 288;
 
 template <int J>
 __device__ __forceinline__ double quad_bcast(double v) {
@@ -152,15 +152,24 @@ __device__ __forceinline__ double quad_bcast(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(kMfWaves *kResLanes) void resample_mfma_kernel(ResampleArgs a) {
-  extern __shared__ double lds[];  // [4 stream groups][kMfRows][16 streams]; later [128 outputs][65]
+// kGroups stream groups of 16 per workgroup.  Four groups (64 streams, 16 waves, one 147 KB workgroup per CU) is the
+// default.  Two groups (32 streams, 8 waves, 74 KB) let two workgroups share a CU so that one computes while the
+// other moves its tile -- measured 70 ms against 53 ms for the same job: halving the reuse of every coefficient
+// load costs more than the overlap wins (AF_RESAMPLER_VARIANT=mfma32 keeps it selectable).
+template <int kGroups>
+__global__ __launch_bounds__(kGroups * 4 * kResLanes) void resample_mfma_kernel(ResampleArgs a) {
+  constexpr int kWaves = kGroups * 4;             // 32 tiles of four outputs over the waves
+  constexpr int kTilesPerWave = 32 / kWaves;
+  constexpr int kStreams = 16 * kGroups;
+  constexpr int kOutStride = kStreams + 1;
+  extern __shared__ double lds[];  // [kGroups][kMfRows][16 streams]; later [128 outputs][kStreams + 1]
   const int tid = threadIdx.x;
   const int lane = tid & (kResLanes - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kResLanes);
   const int m = lane & 15, kq = lane >> 4;
   const int64_t o0 = (int64_t)blockIdx.x * kMfSeg;
   const int n_seg = (int)((a.n_out - o0) < kMfSeg ? (a.n_out - o0) : kMfSeg);
-  const int s0 = blockIdx.y * kResLanes;
+  const int s0 = blockIdx.y * kStreams;
   const int L = a.sinc_len;
   const int stride = L + 2 * kResampleTablePad;
   const int64_t first = a.pos[o0].base;
@@ -170,10 +179,10 @@ __global__ __launch_bounds__(kMfWaves *kResLanes) void resample_mfma_kernel(Resa
 
   // ---- 1. input span -> LDS; lane = (stream m of the group, time offset kq): 512 contiguous LDS bytes per instruction
   {
-    const int g = wave & 3;
+    const int g = wave % kGroups;
     const int s = s0 + 16 * g + m;
     const double *src = a.in + (int64_t)s * a.in_stride;
-    for (int t4 = (wave >> 2) * 4; t4 < rows; t4 += 16) {
+    for (int t4 = (wave / kGroups) * 4; t4 < rows; t4 += 16) {
       const int t = t4 + kq;
       const int64_t gi = first + t;
       double v = 0.0;
@@ -183,14 +192,14 @@ __global__ __launch_bounds__(kMfWaves *kResLanes) void resample_mfma_kernel(Resa
   }
   __syncthreads();
 
-  // ---- 2. two tiles of four outputs per wave
+  // ---- 2. tiles of four outputs
   const int oc = m >> 2, ph = m & 3;  // this lane's column: output oc of the tile, phase ph
-  double res[2][4][4];
+  double res[kTilesPerWave][kGroups][4];
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-    const int ob = (wave * 2 + gi) * 4;
+  for (int gi = 0; gi < kTilesPerWave; ++gi) {
+    const int ob = (wave * kTilesPerWave + gi) * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < kGroups; ++g)
 #pragma unroll
       for (int r = 0; r < 4; ++r) res[gi][g][r] = 0.0;
     if (ob < n_seg) {
@@ -203,71 +212,72 @@ __global__ __launch_bounds__(kMfWaves *kResLanes) void resample_mfma_kernel(Resa
       const int delta_max = (int)(a.pos[o0 + o_last].base - base0);
       const double *__restrict__ bp = a.table + (int)P.sub[ph] * stride + (kResampleTablePad - (int)P.off[ph] - delta) + kq;
       const int ksteps = (L + 2 + delta_max + 3) >> 2;
-      f64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+      f64x4 acc[kGroups];
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) acc[g] = f64x4{0, 0, 0, 0};
       const double *xa = &lds[(row0 + kq) * 16 + m];
 #pragma unroll 8
       for (int kk = 0; kk < ksteps; ++kk) {
         const double b = bp[4 * kk];
         const double *xr = xa + kk * 64;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[0], b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[kMfRows * 16], b, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[2 * kMfRows * 16], b, acc2, 0, 0, 0);
-        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[3 * kMfRows * 16], b, acc3, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[g * kMfRows * 16], b, acc[g], 0, 0, 0);
       }
       // the four phases of one (stream, output) sit in the four lanes of a quad: exchange, then the cubic
       const double f = P.frac;
-#define AF_CUBIC(ACC, G)                                                                                      \
-  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                             \
-    const double v = ACC[r];                                                                                   \
-    res[gi][G][r] = interp_cubic(f, quad_bcast<0>(v), quad_bcast<1>(v), quad_bcast<2>(v), quad_bcast<3>(v));  \
-  }
-      AF_CUBIC(acc0, 0)
-      AF_CUBIC(acc1, 1)
-      AF_CUBIC(acc2, 2)
-      AF_CUBIC(acc3, 3)
-#undef AF_CUBIC
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = acc[g][r];
+          res[gi][g][r] = interp_cubic(f, quad_bcast<0>(v), quad_bcast<1>(v), quad_bcast<2>(v), quad_bcast<3>(v));
+        }
     }
   }
   __syncthreads();
 
-  // ---- 3. transposed store through LDS ([output][65]); D row i = kq + 4 r of stream group g
+  // ---- 3. transposed store through LDS ([output][streams + 1]); D row i = kq + 4 r of stream group g
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-    const int o = (wave * 2 + gi) * 4 + oc;
+  for (int gi = 0; gi < kTilesPerWave; ++gi) {
+    const int o = (wave * kTilesPerWave + gi) * 4 + oc;
     if (ph == 0) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < kGroups; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds[o * kResRowStride + 16 * g + kq + 4 * r] = res[gi][g][r];
+        for (int r = 0; r < 4; ++r) lds[o * kOutStride + 16 * g + kq + 4 * r] = res[gi][g][r];
     }
   }
   __syncthreads();
-  for (int r = wave; r < kResLanes; r += kMfWaves) {
+  for (int r = wave; r < kStreams; r += kWaves) {
     const int s = s0 + r;
     if (s >= a.n_streams) continue;
     double *dst = a.out + (int64_t)s * a.out_stride + o0;
-    for (int t = lane; t < n_seg; t += kResLanes) dst[t] = lds[t * kResRowStride + r];
+    for (int t = lane; t < n_seg; t += kResLanes) dst[t] = lds[t * kOutStride + r];
   }
 }
 
-static hipError_t launch_resample_mfma(const ResampleArgs &a, hipStream_t stream) {
+template <int kGroups>
+static hipError_t launch_resample_mfma_variant(const ResampleArgs &a, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<kGroups>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) return err;
     attr_set = true;
   }
-  const size_t dyn = sizeof(double) * 4 * kMfRows * 16;
-  const dim3 grid((unsigned)((a.n_out + kMfSeg - 1) / kMfSeg), (unsigned)((a.n_streams + kResLanes - 1) / kResLanes));
-  hipLaunchKernelGGL(resample_mfma_kernel, grid, dim3(kMfWaves * kResLanes), dyn, stream, a);
+  const size_t dyn = sizeof(double) * kGroups * kMfRows * 16;
+  const dim3 grid((unsigned)((a.n_out + kMfSeg - 1) / kMfSeg), (unsigned)((a.n_streams + 16 * kGroups - 1) / (16 * kGroups)));
+  hipLaunchKernelGGL(resample_mfma_kernel<kGroups>, grid, dim3(kGroups * 4 * kResLanes), dyn, stream, a);
   return hipGetLastError();
+}
+static hipError_t launch_resample_mfma(const ResampleArgs &a, int variant, hipStream_t stream) {
+  return variant == 2 ? launch_resample_mfma_variant<2>(a, stream) : launch_resample_mfma_variant<4>(a, stream);
 }
 
 // the matrix-core tile needs: 128 outputs' span + the tap round-up inside 288 rows, and a tile's four windows
 // starting within 8 frames of each other (row padding 16)
 bool resample_mfma_ok(double ratio, int sinc_len) {
-  return std::ceil(128.0 / ratio) + sinc_len + 14 <= kMfRows && 3.0 / ratio + 3.0 <= 8.0 && 128 * kResRowStride <= 4 * kMfRows * 16;
+  return std::ceil(128.0 / ratio) + sinc_len + 14 <= kMfRows && 3.0 / ratio + 3.0 <= 8.0;  // (128 x 33 staging fits 2 x 288 x 16)
 }
 
 constexpr int kResMaxRows = 288;  // 288 x 65 x 8 B = 149 760 B of the CU's 160 KB
@@ -304,7 +314,7 @@ hipError_t launch_resample(const double *in, double *out, const ResamplePos *pos
                            double ratio, int variant, hipStream_t stream) {
   ResampleArgs a{in, out, pos, table, n_in, n_out, in_stride, out_stride, n_streams, sinc_len, kResMaxRows};
   if (n_out <= 0 || n_streams <= 0) return hipSuccess;
-  if (variant != 1 && resample_mfma_ok(ratio, sinc_len)) return launch_resample_mfma(a, stream);
+  if (variant != 1 && resample_mfma_ok(ratio, sinc_len)) return launch_resample_mfma(a, variant, stream);
   switch (resample_segment_outputs(ratio, sinc_len)) {
     case 128: return launch_resample_variant<16, 8>(a, stream);
     case 64: return launch_resample_variant<16, 4>(a, stream);
