@@ -177,17 +177,25 @@ __global__ __launch_bounds__(kGroups * 4 * kResLanes) void resample_mfma_kernel(
   int rows = (int)(last - first + 1) + 8;  // + the tap-block round-up of the last tile (zero taps: values only need to be finite)
   if (rows > kMfRows) rows = kMfRows;
 
-  // ---- 1. input span -> LDS; lane = (stream m of the group, time offset kq): 512 contiguous LDS bytes per instruction
+  // ---- 1. input span -> LDS; lane = (stream m of the group, time offset kq): 512 contiguous LDS bytes per instruction.
+  // All of a wave's loads are issued before the first one is consumed (a load-wait-store loop would pay the HBM
+  // latency once per row block).
   {
     const int g = wave % kGroups;
     const int s = s0 + 16 * g + m;
     const double *src = a.in + (int64_t)s * a.in_stride;
-    for (int t4 = (wave / kGroups) * 4; t4 < rows; t4 += 16) {
-      const int t = t4 + kq;
+    constexpr int kBlocks = (kMfRows / 4 + 3) / 4;  // row blocks of 4 per wave (four waves share a stream group)
+    double v[kBlocks];
+#pragma unroll
+    for (int i = 0; i < kBlocks; ++i) {
+      const int t = ((wave / kGroups) + 4 * i) * 4 + kq;
       const int64_t gi = first + t;
-      double v = 0.0;
-      if (s < a.n_streams && t < rows && gi >= 0 && gi < a.n_in) v = src[gi];
-      if (t < rows) lds[(g * kMfRows + t) * 16 + m] = v;
+      v[i] = (s < a.n_streams && t < rows && gi >= 0 && gi < a.n_in) ? src[gi] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < kBlocks; ++i) {
+      const int t = ((wave / kGroups) + 4 * i) * 4 + kq;
+      if (t < rows) lds[(g * kMfRows + t) * 16 + m] = v[i];
     }
   }
   __syncthreads();
@@ -216,12 +224,28 @@ __global__ __launch_bounds__(kGroups * 4 * kResLanes) void resample_mfma_kernel(
 #pragma unroll
       for (int g = 0; g < kGroups; ++g) acc[g] = f64x4{0, 0, 0, 0};
       const double *xa = &lds[(row0 + kq) * 16 + m];
-#pragma unroll 8
-      for (int kk = 0; kk < ksteps; ++kk) {
-        const double b = bp[4 * kk];
-        const double *xr = xa + kk * 64;
+      // coefficients are fetched four tap blocks ahead of the MFMAs that use them
+      double bq[4];
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[g * kMfRows * 16], b, acc[g], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) bq[u] = bp[4 * (u < ksteps ? u : ksteps - 1)];
+      for (int kk = 0; kk < ksteps; kk += 4) {
+        double bn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int nk = kk + 4 + u;
+          bn[u] = bp[4 * (nk < ksteps ? nk : ksteps - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (kk + u < ksteps) {
+            const double *xr = xa + (kk + u) * 64;
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+              acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[g * kMfRows * 16], bq[u], acc[g], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bq[u] = bn[u];
       }
       // the four phases of one (stream, output) sit in the four lanes of a quad: exchange, then the cubic
       const double f = P.frac;
