@@ -226,10 +226,13 @@ int upload_initial_state(af_engine *e) {
 int ensure_started(af_engine *e) {
   AF_HIP(hipSetDevice(e->device));
   if (!e->started) {
-    if (e->proto.limiter_enabled && e->proto.limiter.lookahead_samples > af::kLdsLookaheadMax)
-      return fail(AF_ERR_UNSUPPORTED, "limiter lookahead of %d samples exceeds the LDS-resident ring (%d)",
-                  e->proto.limiter.lookahead_samples, af::kLdsLookaheadMax);
     export_params(e);
+    // the limiter's delay ring and suffix maxima live in LDS: kernel 3 (16 streams per workgroup) holds ~1000 samples
+    // of lookahead (2 ms at 384 kHz = 768), kernels 1 and 2 (64 streams) ~127 / ~180
+    if (e->proto.limiter_enabled &&
+        af::quad_kernel_dynamic_lds(e->host_params.n_eq_sections, e->proto.limiter.lookahead_samples, true) > af::kMaxLdsBytes)
+      return fail(AF_ERR_UNSUPPORTED, "limiter lookahead of %d samples exceeds what the LDS-resident ring holds",
+                  e->proto.limiter.lookahead_samples);
     if (e->proto.compressor_enabled && e->proto.compressor.auto_makeup_enabled) {
       if (e->host_params.comp.meter_slots <= 0)
         return fail(AF_ERR_UNSUPPORTED, "auto-makeup needs a control block that divides the 400 ms loudness window "
@@ -321,6 +324,9 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     return fail(AF_ERR_UNSUPPORTED, "the quad kernel does not build auto-makeup or the EQ-before-de-esser order; use AF_KERNEL_PHASED");
   if (kernel == AF_KERNEL_PHASED && !ring_fits)
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for this configuration");
+  if (kernel == AF_KERNEL_LANE_PER_STREAM && af::lane_kernel_dynamic_lds(run.lim.lookahead_samples) > 90 * 1024)
+    return fail(AF_ERR_UNSUPPORTED, "the lane-per-stream kernel cannot hold a limiter lookahead of %d samples in LDS",
+                run.lim.lookahead_samples);
   if (auto_makeup && kernel != AF_KERNEL_PHASED)
     return fail(AF_ERR_UNSUPPORTED, "compressor auto-makeup is only built into the token-ring kernel");
   e->last_kernel_used = kernel;

@@ -143,6 +143,25 @@ def test_dynamics_aliasing_report_pins(mi, oracle):
         assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
 
 
+def test_dynamics_aliasing_report_pins_at_192_khz(mi, oracle):
+    """The report's 192 kHz column (evaluation/dynamics-aliasing-report.json): the 2 ms lookahead is 384 samples there,
+    which only the 16-stream kernel holds in LDS (AUTO routes to it; the 64-stream kernels refuse)."""
+    want_gr = {"carrier_8k": 17.137773513793945, "carrier_11k": 17.001239776611328,
+               "carrier_15k": 16.64676856994629, "carrier_18k": 16.35672378540039}
+    variant = os.environ.get("AF_KERNEL_VARIANT", "")
+    for name, carrier, mod in S.ALIASING_CASES:
+        x = S.aliasing_signal(192_000, carrier, mod)
+        if not variant.startswith("quad"):
+            with pytest.raises(NotImplementedError):
+                mi.simulate_auto_eq_chain(x, 192_000, S.ALIASING_BANDS, S.ALIASING_SETTINGS)
+            return
+        got = mi.simulate_auto_eq_chain(x, 192_000, S.ALIASING_BANDS, S.ALIASING_SETTINGS)
+        want = oracle.simulate_auto_eq_chain(x, 192_000, S.ALIASING_BANDS, S.ALIASING_SETTINGS)
+        assert abs(got["compressor_gain_reduction_db"] - want_gr[name]) <= 1e-5 * want_gr[name]
+        max_abs, rms = _err(got["output_audio"], want["output_audio"])
+        assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
+
+
 def test_kat_chain_without_deesser_and_adaptive_release(mi, oracle):
     """The golden test's EQ/compressor/limiter settings (tests.rs:1795-1808) minus the de-esser,
     480-sample blocks, legacy EQ setters (72-sample coefficient crossfade at the start)."""
