@@ -162,6 +162,24 @@ def test_dynamics_aliasing_report_pins_at_192_khz(mi, oracle):
         assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
 
 
+@pytest.mark.parametrize("fs", [44_100, 96_000])
+def test_other_sample_rates(mi, oracle, fs):
+    """Every rate-dependent constant (RBJ coefficients, time constants, lookahead = round(ms * fs / 1000), crossfade
+    length) comes from the host mirror: same chain, same fixtures, at 44.1 kHz (88-sample lookahead) and 96 kHz (192)."""
+    variant = os.environ.get("AF_KERNEL_VARIANT", "")
+    x = S.kat_signal(120)
+    settings = S.limiter_settings(2.0)
+    if fs == 96_000 and not (variant.startswith("quad") or variant == ""):
+        with pytest.raises(NotImplementedError):
+            mi.simulate_auto_eq_chain(x, fs, S.LIMITER_BANDS, settings)
+        return
+    want = oracle.simulate_auto_eq_chain(x, fs, S.LIMITER_BANDS, settings)
+    got = mi.simulate_auto_eq_chain(x, fs, S.LIMITER_BANDS, settings)
+    max_abs, rms = _err(got["output_audio"], want["output_audio"])
+    assert max_abs <= MAX_ABS and rms <= MAX_RMS, (fs, max_abs, rms)
+    _compare_dicts(got, want, exact_keys=("true_peak_limited_events", "processed_samples"))
+
+
 def test_kat_chain_without_deesser_and_adaptive_release(mi, oracle):
     """The golden test's EQ/compressor/limiter settings (tests.rs:1795-1808) minus the de-esser,
     480-sample blocks, legacy EQ setters (72-sample coefficient crossfade at the start)."""
