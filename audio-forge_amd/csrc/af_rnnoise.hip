@@ -938,16 +938,19 @@ __device__ __forceinline__ float tansig_approx(const float *table, float x) {
 }
 __device__ __forceinline__ float sigmoid_approx(const float *table, float x) { return .5f + .5f * tansig_approx(table, .5f * x); }
 
-// One 16(streams) x 16(units) tile: acc = bias; acc += A[16][K] * W[K][N]  as a k-ordered fmaf chain
+// One 16(streams) x 16(units) tile: acc = bias; acc += A[16][K] * W[K][N]  as a k-ordered fmaf chain.  W is the
+// int8 matrix in LDS (exactly the model's weights; the 1/256 scale is applied to the sum as in rnn.c).
 template <int LDA>
-__device__ __forceinline__ v4f mfma_tile(const float (*A)[LDA], const float *W, const float *bias, int k_pad, int n_pad,
+__device__ __forceinline__ v4f mfma_tile(const float (*A)[LDA], const int8_t *W, const float *bias, int k_pad, int n_pad,
                                          int tile, int lane) {
   const int col = lane & 15, kq = lane >> 4;
   const float bv = bias[tile * 16 + col];
   v4f acc = {bv, bv, bv, bv};
+  const int8_t *wp = W + kq * n_pad + tile * 16 + col;
+#pragma unroll 4
   for (int k0 = 0; k0 < k_pad; k0 += 4) {
-    const float av = A[col][k0 + kq];                                 // A[i = lane&15][k = lane>>4]
-    const float wv = W[(size_t)(k0 + kq) * n_pad + tile * 16 + col];  // B[k = lane>>4][j = lane&15]
+    const float av = A[col][k0 + kq];           // A[i = lane&15][k = lane>>4]
+    const float wv = (float)wp[k0 * n_pad];     // B[k = lane>>4][j = lane&15]
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc, 0, 0, 0);
   }
   return acc;  // acc[reg]: row (stream) = (lane>>4)*4 + reg, column (unit) = tile*16 + (lane&15)
@@ -955,7 +958,10 @@ __device__ __forceinline__ v4f mfma_tile(const float (*A)[LDA], const float *W, 
 
 extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, RnnDeviceWeights w) {
   __shared__ RnnLds L;
+  extern __shared__ __attribute__((aligned(16))) int8_t w8[];  // all eleven matrices, staged once per workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < w.w8_bytes / 16; i += 256)
+    reinterpret_cast<uint4 *>(w8)[i] = reinterpret_cast<const uint4 *>(w.w8)[i];
   const int s0 = blockIdx.x * 16;
   const float kScale = 1.f / 256;
   for (int i = tid; i < 201; i += 256) L.tansig[i] = w.tansig[i];
@@ -983,7 +989,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     __syncthreads();
     // ---- input_dense 42 -> 24 (tanh): 2 tiles on waves 0,1
     if (wave < 2) {
-      const v4f acc = mfma_tile<kRnnFeatPad>(L.in0, w.dense_w, w.dense_b, kDimDense.k_pad, kDimDense.n_pad, wave, lane);
+      const v4f acc = mfma_tile<kRnnFeatPad>(L.in0, w8 + w.off8[0], w.dense_b, kDimDense.k_pad, kDimDense.n_pad, wave, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = wave * 16 + col;
         if (unit < 24) L.dense[row][unit] = tansig_approx(L.tansig, kScale * acc[r]);
@@ -998,7 +1004,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     __syncthreads();
     {  // z, r: 2 gates x 2 tiles = 4 tiles, one per wave
       const int gate = wave >> 1, tile = wave & 1;
-      const v4f acc = mfma_tile<48>(L.vcat, w.vad_w[gate], w.vad_b[gate], kDimVad.k_pad, kDimVad.n_pad, tile, lane);
+      const v4f acc = mfma_tile<48>(L.vcat, w8 + w.off8[1 + gate], w.vad_b[gate], kDimVad.k_pad, kDimVad.n_pad, tile, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = tile * 16 + col;
         if (unit < 24) (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
@@ -1011,7 +1017,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     }
     __syncthreads();
     if (wave < 2) {
-      const v4f acc = mfma_tile<48>(L.vcat, w.vad_w[2], w.vad_b[2], kDimVad.k_pad, kDimVad.n_pad, wave, lane);
+      const v4f acc = mfma_tile<48>(L.vcat, w8 + w.off8[3], w.vad_b[2], kDimVad.k_pad, kDimVad.n_pad, wave, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = wave * 16 + col;
         if (unit < 24) {
@@ -1037,7 +1043,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     __syncthreads();
     for (int t = wave; t < 6; t += 4) {  // z, r: 2 gates x 3 tiles
       const int gate = t / 3, tile = t % 3;
-      const v4f acc = mfma_tile<140>(L.ncat, w.noise_w[gate], w.noise_b[gate], kDimNoise.k_pad, kDimNoise.n_pad, tile, lane);
+      const v4f acc = mfma_tile<140>(L.ncat, w8 + w.off8[4 + gate], w.noise_b[gate], kDimNoise.k_pad, kDimNoise.n_pad, tile, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = tile * 16 + col;
         (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
@@ -1050,7 +1056,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     }
     __syncthreads();
     if (wave < 3) {
-      const v4f acc = mfma_tile<140>(L.ncat, w.noise_w[2], w.noise_b[2], kDimNoise.k_pad, kDimNoise.n_pad, wave, lane);
+      const v4f acc = mfma_tile<140>(L.ncat, w8 + w.off8[6], w.noise_b[2], kDimNoise.k_pad, kDimNoise.n_pad, wave, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = wave * 16 + col;
         float sum = kScale * acc[r];
@@ -1074,7 +1080,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     __syncthreads();
     for (int t = wave; t < 12; t += 4) {  // z, r: 2 gates x 6 tiles
       const int gate = t / 6, tile = t % 6;
-      const v4f acc = mfma_tile<212>(L.dcat, w.den_w[gate], w.den_b[gate], kDimDenoise.k_pad, kDimDenoise.n_pad, tile, lane);
+      const v4f acc = mfma_tile<212>(L.dcat, w8 + w.off8[7 + gate], w.den_b[gate], kDimDenoise.k_pad, kDimDenoise.n_pad, tile, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = tile * 16 + col;
         (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
@@ -1087,7 +1093,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     }
     __syncthreads();
     for (int t = wave; t < 6; t += 4) {
-      const v4f acc = mfma_tile<212>(L.dcat, w.den_w[2], w.den_b[2], kDimDenoise.k_pad, kDimDenoise.n_pad, t, lane);
+      const v4f acc = mfma_tile<212>(L.dcat, w8 + w.off8[9], w.den_b[2], kDimDenoise.k_pad, kDimDenoise.n_pad, t, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = t * 16 + col;
         float sum = kScale * acc[r];
@@ -1104,7 +1110,7 @@ extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, Rn
     __syncthreads();
     // ---- denoise_output 96 -> 22 (sigmoid), then g = max(g, 0.6 lastg)
     if (wave < 2) {
-      const v4f acc = mfma_tile<96>(L.den_state, w.out_w, w.out_b, kDimOut.k_pad, kDimOut.n_pad, wave, lane);
+      const v4f acc = mfma_tile<96>(L.den_state, w8 + w.off8[10], w.out_b, kDimOut.k_pad, kDimOut.n_pad, wave, lane);
       for (int r = 0; r < 4; ++r) {
         const int row = rq * 4 + r, unit = wave * 16 + col;
         if (unit < kRnnBands && s0 + row < a.n_streams) {
@@ -1289,7 +1295,15 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
-  hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), 0, stream, a, w);
+  {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(supp_rnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (err != hipSuccess) return err;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), (size_t)w.w8_bytes, stream, a, w);
+  }
   hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);
   return hipGetLastError();

@@ -62,6 +62,11 @@ struct RnnDeviceWeights {
   const float *den_w[3], *den_b[3];         // [212][96]
   const float *out_w, *out_b;               // [96][32]
   const float *tansig;                      // [201]
+  // the same eleven matrices as int8 (the model's native precision), [K_pad][N_pad] each, one 16-byte-aligned blob:
+  // the network kernel keeps them in LDS (90 KB) so that no step of its frame-to-frame chain waits on L2
+  const int8_t *w8;
+  int32_t off8[11];                         // dense, vad z r h, noise z r h, denoise z r h, out
+  int32_t w8_bytes;
 };
 
 struct SuppTables {

@@ -71,6 +71,7 @@ struct SuppressorHost {
   bool weights_dirty = true;
   // device side
   float *d_blob = nullptr;   // all f32 matrices + tables, one allocation
+  int8_t *d_w8 = nullptr;    // the matrices again as int8 (what the network kernel stages into LDS)
   size_t blob_floats = 0;
   RnnDeviceWeights dw{};
   SuppTables tables{};
@@ -178,6 +179,26 @@ struct SuppressorHost {
       dw.den_w[g] = d_blob + ew[g];
       dw.den_b[g] = d_blob + eb[g];
     }
+    {  // int8 copies of the eleven matrices, same padded layout (every entry of the f32 blob is a small integer)
+      const size_t offs[11] = {dw_off, vw[0], vw[1], vw[2], nw[0], nw[1], nw[2], ew[0], ew[1], ew[2], ow_off};
+      const RnnLayerDims dims[11] = {kDimDense, kDimVad, kDimVad, kDimVad, kDimNoise, kDimNoise, kDimNoise,
+                                     kDimDenoise, kDimDenoise, kDimDenoise, kDimOut};
+      std::vector<int8_t> w8;
+      for (int i = 0; i < 11; ++i) {
+        dw.off8[i] = (int32_t)w8.size();
+        const size_t count = (size_t)dims[i].k_pad * dims[i].n_pad;
+        for (size_t j = 0; j < count; ++j) w8.push_back((int8_t)blob[offs[i] + j]);
+        while (w8.size() % 16) w8.push_back(0);
+      }
+      dw.w8_bytes = (int32_t)w8.size();
+      if (!d_w8) {
+        hipError_t e8 = hipMalloc(&d_w8, w8.size());
+        if (e8 != hipSuccess) return e8;
+      }
+      hipError_t e8 = hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice);
+      if (e8 != hipSuccess) return e8;
+      dw.w8 = d_w8;
+    }
     dw.tansig = d_blob + tansig_off;
     tables.half_window = d_blob + win_off;
     tables.dct = d_blob + dct_off;
@@ -234,6 +255,8 @@ struct SuppressorHost {
   void release_all() {
     release_workspace();
     (void)hipFree(d_blob);
+    (void)hipFree(d_w8);
+    d_w8 = nullptr;
     (void)hipFree(d_state);
     d_blob = d_state = nullptr;
     blob_floats = 0;
