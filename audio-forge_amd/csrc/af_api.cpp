@@ -107,6 +107,7 @@ struct af_engine {
   int64_t io_capacity = 0;     // floats
   hipStream_t last_stream = nullptr;
   af::SuppressorHost supp;
+  bool borrowed_streams = false;                         // AF_SERIAL_STREAMS: the side streams alias the caller's
   hipStream_t aux_stream = nullptr;                      // chain launches while the suppressor fills the chip
   hipStream_t pre_stream = nullptr;                      // the suppressor's sample-serial pre-pass, two windows ahead
   hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
@@ -501,6 +502,7 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = nullptr;
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
   if (e->ana_stream) (void)hipStreamDestroy(e->ana_stream);
@@ -785,6 +787,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!windows_align) window = frames;  // ragged tail: one window (workspace permitting)
   window = std::min<int64_t>(window, frames);
   AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
+  if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
+    e->aux_stream = e->pre_stream = e->ana_stream = stream;
+    e->borrowed_streams = true;
+  }
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
