@@ -23,6 +23,8 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
+hipError_t launch_chain_ring_part(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int part,
+                                  hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
                              hipStream_t stream);
 size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
@@ -75,6 +77,7 @@ struct af_engine {
   bool params_dirty = true;
   int kernel = AF_KERNEL_AUTO;
   int ring_variant = 0;
+  bool chain_split = false;  // two-launch form of the token-ring chain (measured slower: DESIGN.md 4.2c)
   bool timing = false;
   int64_t samples_processed = 0;
   int64_t last_blocks = 0;
@@ -93,6 +96,14 @@ struct af_engine {
   af::BlockStats *d_stats_pre = nullptr;   // rows of the pre-pass launch (auto-makeup)
   int64_t stats_pre_capacity = 0;
   af::ChainParams *d_params_pre = nullptr;
+  af::ChainParams uploaded_pre{};          // what d_params_pre holds (tracked by the split chain only)
+  bool uploaded_pre_valid = false;
+  double *d_side[2] = {nullptr, nullptr};  // split chain: gain-reduction targets of two windows in flight
+  int64_t side_capacity = 0;               // doubles per buffer
+  hipStream_t tail_stream = nullptr;       // split chain: the tail launches
+  hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
+  int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tail_ms_events;  // timing brackets of the tail launches of the last call
   af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
   af::ChainParams *d_params_de = nullptr;  // the de-esser pass reads the unedited parameter block
   af::ChainParams uploaded_de{};
@@ -396,6 +407,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
       AF_HIP(hipStreamSynchronize(stream));
       e->uploaded_valid = false;  // d_params now holds the post-pass variant
+      e->uploaded_pre_valid = false;
       AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
       af::LaunchArgs a1 = a;
       a1.params = e->d_params_pre;
@@ -455,6 +467,102 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   return AF_OK;
 }
 
+// The chain of one window as two launches on two streams (af_ring_kernel.hip, kMode 1 / 2): the head of window w+1
+// overlaps the tail of window w on other CUs.  Available for the plain compressor path of the token-ring kernel.
+bool chain_split_eligible(const af_engine *e, const af::ChainParams &run) {
+  static const int env_choice = [] {  // AF_CHAIN_SPLIT=0/1 overrides the engine's setting (A/B runs)
+    const char *env = std::getenv("AF_CHAIN_SPLIT");
+    return env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
+  }();
+  if (!(env_choice >= 0 ? env_choice != 0 : e->chain_split)) return false;
+  if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED) return false;
+  if (e->ring_variant != 0 && e->ring_variant != 1604) return false;
+  if (!(run.flags & af::kFlagCompressor) || run.comp.auto_makeup_enabled || (run.flags & af::kFlagDeesser)) return false;
+  if (run.control_block % 4 != 0) return false;
+  // decided once per call: sized for the crossfade layout so that every window of the call takes the same route
+  return af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, true) <= af::kMaxLdsBytes;
+}
+
+int launch_chain_split(af_engine *e, const af::ChainParams &run, const float *in, float *out, int64_t n_samples,
+                       int64_t stream_stride, int32_t layout, int64_t samples_before, af::BlockStats *stats,
+                       int64_t window_index, hipStream_t head_stream, hipStream_t tail_stream, hipEvent_t head_done,
+                       hipEvent_t tail_done, hipEvent_t side_free) {
+  const int cb = run.control_block;
+  const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
+  bool any_xf = false;
+  for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
+  e->last_kernel_used = AF_KERNEL_PHASED;
+  const int64_t side_need = n_samples * e->n_streams;
+  if (side_need > e->side_capacity) {
+    AF_HIP(hipDeviceSynchronize());
+    for (double *&p : e->d_side) {
+      if (p) AF_HIP(hipFree(p));
+      p = nullptr;
+      AF_HIP(hipMalloc(&p, sizeof(double) * side_need));
+    }
+    e->side_capacity = side_need;
+  }
+  const uint32_t front_flags = af::kFlagInputScrub | af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
+  af::ChainParams head = run, tail = run;
+  head.flags = (head.flags & ~af::kFlagLimiter) | af::kFlagSplitHead;
+  tail.flags = (tail.flags & ~(af::kFlagEq | front_flags)) | af::kFlagSplitTail;
+  if (!e->uploaded_pre_valid || std::memcmp(&e->uploaded_pre, &head, sizeof head) != 0) {
+    e->uploaded_pre = head;  // engine-owned copy: stays valid until the async copy has run
+    AF_HIP(hipMemcpyAsync(e->d_params_pre, &e->uploaded_pre, sizeof head, hipMemcpyHostToDevice, head_stream));
+    AF_HIP(hipStreamSynchronize(head_stream));  // rare: first launch, and while EQ crossfades advance
+    e->uploaded_pre_valid = true;
+  }
+  if (!e->uploaded_valid || std::memcmp(&e->uploaded, &tail, sizeof tail) != 0) {
+    e->uploaded = tail;
+    AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof tail, hipMemcpyHostToDevice, tail_stream));
+    AF_HIP(hipStreamSynchronize(tail_stream));
+    e->uploaded_valid = true;
+  }
+  af::LaunchArgs a{};
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.in = in;
+  a.out = out;
+  a.stats = stats;
+  a.status = e->d_status;
+  a.params = e->d_params_pre;
+  a.n_samples = n_samples;
+  a.stream_stride = stream_stride;
+  a.samples_before = samples_before;
+  a.n_streams = e->n_streams;
+  a.layout = layout;
+  a.side = e->d_side[window_index & 1];
+  a.side_stride = n_samples;
+  hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
+  if (e->timing) {
+    AF_HIP(hipEventCreate(&t0));
+    AF_HIP(hipEventCreate(&t1));
+    AF_HIP(hipEventCreate(&t2));
+    AF_HIP(hipEventCreate(&t3));
+  }
+  // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
+  AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, head_stream));
+  if (side_free) AF_HIP(hipStreamWaitEvent(head_stream, side_free, 0));  // the tail two windows back has read this buffer
+  if (t0) AF_HIP(hipEventRecord(t0, head_stream));
+  AF_HIP(af::launch_chain_ring_part(a, head.n_eq_sections, head.lim.lookahead_samples, any_xf, 1, head_stream));
+  if (t1) AF_HIP(hipEventRecord(t1, head_stream));
+  AF_HIP(hipEventRecord(head_done, head_stream));
+  AF_HIP(hipStreamWaitEvent(tail_stream, head_done, 0));
+  a.params = e->d_params;
+  a.in = out;
+  if (t2) AF_HIP(hipEventRecord(t2, tail_stream));
+  AF_HIP(af::launch_chain_ring_part(a, tail.n_eq_sections, tail.lim.lookahead_samples, any_xf, 2, tail_stream));
+  if (t3) AF_HIP(hipEventRecord(t3, tail_stream));
+  AF_HIP(hipEventRecord(tail_done, tail_stream));
+  e->last_launches += 2;
+  if (e->timing) {
+    e->chain_ms_events.push_back({t0, t1});
+    e->tail_ms_events.push_back({t2, t3});
+  }
+  advance_crossfades(e, n_samples);
+  return AF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -502,7 +610,12 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = nullptr;
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = nullptr;
+  if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
+  if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
+  for (double *p : e->d_side)
+    if (p) (void)hipFree(p);
+  for (auto &pr : e->tail_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
   if (e->ana_stream) (void)hipStreamDestroy(e->ana_stream);
@@ -690,6 +803,11 @@ int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk) {
   e->ring_variant = v;
   return AF_OK;
 }
+int af_engine_set_chain_split(af_engine *e, int32_t on) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  e->chain_split = on != 0;
+  return AF_OK;
+}
 int af_engine_last_kernel(const af_engine *e) { return e ? e->last_kernel_used : 0; }
 int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
@@ -739,6 +857,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   e->chain_ms_events.clear();
+  for (auto &pr : e->tail_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  e->tail_ms_events.clear();
 
   if (!e->supp.enabled) {
     int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
@@ -787,13 +907,88 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!windows_align) window = frames;  // ragged tail: one window (workspace permitting)
   window = std::min<int64_t>(window, frames);
   AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
+  // Window schedule.  The first chain launch cannot start before one window has been through the pre-pass, the analysis
+  // and the synthesis, and the last chain launch runs after everything else is done: with uniform windows that is ~2.5
+  // window times of a 20-window call during which most of the chip idles.  So the call opens with short windows that
+  // double up to the full size and closes with the mirror image (every size a whole number of control blocks).
+  std::vector<int64_t> win_f0, win_nf;
+  {
+    static const bool ramp = [] {
+      const char *env = std::getenv("AF_SUPP_RAMP");
+      return !env || std::atoi(env) != 0;
+    }();
+    std::vector<int64_t> up;
+    for (int64_t n = ((4 + unit - 1) / unit) * unit; n < window; n *= 2) up.push_back(n);
+    int64_t up_total = 0;
+    for (int64_t n : up) up_total += n;
+    if (ramp && windows_align && !up.empty() && frames >= 2 * up_total + 2 * window) {
+      int64_t f = 0;
+      for (int64_t n : up) { win_f0.push_back(f); win_nf.push_back(n); f += n; }
+      const int64_t body_end = frames - up_total;
+      while (f < body_end) {
+        const int64_t n = std::min<int64_t>(window, body_end - f);
+        win_f0.push_back(f); win_nf.push_back(n); f += n;
+      }
+      for (auto it = up.rbegin(); it != up.rend(); ++it) { win_f0.push_back(f); win_nf.push_back(*it); f += *it; }
+    } else {
+      for (int64_t f = 0; f < frames; f += window) { win_f0.push_back(f); win_nf.push_back(std::min<int64_t>(window, frames - f)); }
+    }
+  }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = stream;
+    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = stream;
     e->borrowed_streams = true;
+  }
+  const bool split = chain_split_eligible(e, run);
+
+  if (!e->aux_stream) {
+    // CU partition.  A 16-wave chain workgroup needs a whole CU (it fills the register file), and the suppressor's
+    // kernels keep thousands of small, some of them long-lived, workgroups in flight: left to the dispatcher, every chain
+    // launch waits for CUs to drain and runs beside strangers.  So the chain stream is confined to as many CUs as it has
+    // workgroups (mask bits 0.. select the same CU indices on every XCD: tools/probe/cu_mask_probe.hip) and the
+    // suppressor's streams to the rest; neither side ever waits for the other's workgroups to leave.
+    int chain_cus = 0;
+    const char *env = std::getenv("AF_CU_PARTITION");
+    const int chain_groups = (e->n_streams + 63) / 64;
+    hipDeviceProp_t prop;
+    AF_HIP(hipGetDeviceProperties(&prop, e->device));
+    const int total_cus = prop.multiProcessorCount;
+    if (!(env && std::atoi(env) == 0) && total_cus % 32 == 0 && total_cus <= 1024) {
+      chain_cus = env && std::atoi(env) > 0 ? std::atoi(env) : ((chain_groups + 7) / 8) * 8;
+      if (chain_cus * 2 > total_cus) chain_cus = 0;  // a chain that wants half the chip or more shares all of it
+    }
+    if (chain_cus > 0) {
+      std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u);
+      for (int bit = 0; bit < total_cus; ++bit) (bit < chain_cus ? chain_mask : rest_mask)[bit >> 5] |= 1u << (bit & 31);
+      hipError_t err = hipExtStreamCreateWithCUMask(&e->aux_stream, (uint32_t)chain_mask.size(), chain_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err != hipSuccess) {  // platform without queue CU masks: plain streams
+        (void)hipGetLastError();
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream}) {
+          if (*sp) (void)hipStreamDestroy(*sp);
+          *sp = nullptr;
+        }
+        chain_cus = 0;
+      }
+    }
+    e->partition_chain_cus = chain_cus;
   }
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
+  const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
+  if (split && !e->tail_stream) {
+    if (e->partition_chain_cus > 0) {  // the tail shares the chain's CUs (reserve twice the workgroup count for a split chain)
+      hipDeviceProp_t prop;
+      AF_HIP(hipGetDeviceProperties(&prop, e->device));
+      std::vector<uint32_t> chain_mask(prop.multiProcessorCount / 32, 0u);
+      for (int bit = 0; bit < e->partition_chain_cus; ++bit) chain_mask[bit >> 5] |= 1u << (bit & 31);
+      AF_HIP(hipExtStreamCreateWithCUMask(&e->tail_stream, (uint32_t)chain_mask.size(), chain_mask.data()));
+    } else {
+      AF_HIP(hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking));
+    }
+  }
   int64_t blocks_done = 0;
   size_t ev_index = 0;
   auto next_event = [&](hipEvent_t *out_ev) -> int {
@@ -812,6 +1007,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
     AF_HIP(hipStreamWaitEvent(e->pre_stream, ev, 0));
     AF_HIP(hipStreamWaitEvent(e->ana_stream, ev, 0));
+    if (split) AF_HIP(hipStreamWaitEvent(e->tail_stream, ev, 0));
+    if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
@@ -840,33 +1037,44 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     sa.chain_st32 = e->d_st32;
     sa.f64_pre_z1 = af::kPreZ1;
     sa.f32_dc_x1 = af::kDcX1;
-    if (index > 0) {  // history = tail of the previous window's buffer (all earlier windows are `window` frames long)
+    if (index > 0) {  // history = tail of the previous window's buffer
       sa.xh_prev = e->supp.d_xh + (size_t)((index - 1) % kXh) * e->supp.xh_floats;
-      sa.xh_prev_stride = af::kPitchBuf + window * af::kRnnFrame;
+      sa.xh_prev_stride = af::kPitchBuf + win_nf[index - 1] * af::kRnnFrame;
     }
     return sa;
   };
-  const int64_t n_windows = (frames + window - 1) / window;
-  std::vector<hipEvent_t> pre_done(n_windows), ana_done(n_windows), syn_done(n_windows);
+  const int64_t n_windows = (int64_t)win_f0.size();
+  std::vector<hipEvent_t> pre_done(n_windows), ana_done(n_windows), syn_done(n_windows), head_done(n_windows), tail_done(n_windows);
+  std::vector<hipEvent_t> rnn_done(n_windows);
   for (int64_t w = 0; w < n_windows; ++w) {
+    if (int rc = next_event(&rnn_done[w])) return rc;
     if (int rc = next_event(&pre_done[w])) return rc;
     if (int rc = next_event(&ana_done[w])) return rc;
     if (int rc = next_event(&syn_done[w])) return rc;
+    if (split) {
+      if (int rc = next_event(&head_done[w])) return rc;
+      if (int rc = next_event(&tail_done[w])) return rc;
+    }
   }
   // Stages are enqueued in pipeline order (the pre-pass two windows and the analysis one window ahead of the
   // synthesis), so that every event a stage waits on has been recorded before the wait is enqueued.
   auto enqueue_pre = [&](int64_t w) -> int {
-    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
+    const int64_t f0 = win_f0[w], nf = win_nf[w];
     if (w >= kXh) AF_HIP(hipStreamWaitEvent(e->pre_stream, syn_done[w - kXh], 0));  // its model-input buffer is free
     AF_HIP(af::launch_suppressor_prefilter(window_args(f0, nf, w), e->pre_stream));
     AF_HIP(hipEventRecord(pre_done[w], e->pre_stream));
     return AF_OK;
   };
   auto enqueue_ana = [&](int64_t w) -> int {
-    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
+    const int64_t f0 = win_f0[w], nf = win_nf[w];
     AF_HIP(hipStreamWaitEvent(e->ana_stream, pre_done[w], 0));
     if (w >= 2) AF_HIP(hipStreamWaitEvent(e->ana_stream, syn_done[w - 2], 0));  // its spectrum / record buffers are free
-    AF_HIP(af::launch_suppressor_analysis(window_args(f0, nf, w), e->supp.tables, e->ana_stream));
+    static const bool order_pitch = [] {  // AF_ORDER_PITCH=1: hold the pitch search back until the previous window's network ran
+      const char *env = std::getenv("AF_ORDER_PITCH");
+      return env && std::atoi(env) != 0;  // off: it only moves the starvation to the resynthesis kernel (313 vs 296 ms)
+    }();
+    AF_HIP(af::launch_suppressor_analysis(window_args(f0, nf, w), e->supp.tables, e->ana_stream,
+                                          (order_pitch && w >= 1) ? rnn_done[w - 1] : nullptr));
     AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));
     return AF_OK;
   };
@@ -874,10 +1082,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (int rc = enqueue_pre(w)) return rc;
   if (int rc = enqueue_ana(0)) return rc;
   for (int64_t w = 0; w < n_windows; ++w) {
-    const int64_t f0 = w * window, nf = std::min<int64_t>(window, frames - f0);
-    AF_HIP(hipStreamWaitEvent(stream, ana_done[w], 0));
-    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, stream));
-    AF_HIP(hipEventRecord(syn_done[w], stream));
+    const int64_t f0 = win_f0[w], nf = win_nf[w];
+    AF_HIP(hipStreamWaitEvent(syn, ana_done[w], 0));
+    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w]));
+    AF_HIP(hipEventRecord(syn_done[w], syn));
     e->last_launches += 7;
     if (w + 2 < n_windows)
       if (int rc = enqueue_pre(w + 2)) return rc;
@@ -886,20 +1094,36 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(e->aux_stream, syn_done[w], 0));
     const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
-    int rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
-                                  e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream,
-                                  stream);
+    static const bool diag_skip_chain = std::getenv("AF_DIAG_SKIP_CHAIN") != nullptr;  // timing experiments only
+    int rc = AF_OK;
+    if (diag_skip_chain) {
+    } else if (split) {
+      // head of window w on the chain stream, tail on its own stream: tail(w) overlaps head(w+1) on other CUs
+      rc = launch_chain_split(e, run, out + seg0, out + seg0, seg_n, stream_stride, layout, e->samples_processed + seg0,
+                              e->d_stats + blocks_done * e->n_streams, w, e->aux_stream, e->tail_stream, head_done[w],
+                              tail_done[w], w >= 2 ? tail_done[w - 2] : nullptr);
+    } else {
+      rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
+                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream);
+    }
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
     blocks_done += (seg_n + cb - 1) / cb;
   }
-  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, stream));  // last suppressor kernel done
+  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, syn));  // last suppressor kernel done
+  if (syn != stream && n_windows > 0) AF_HIP(hipStreamWaitEvent(stream, syn_done[n_windows - 1], 0));
   {
     hipEvent_t ev;
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
+    if (split) {
+      hipEvent_t ev2;
+      if (int rc = next_event(&ev2)) return rc;
+      AF_HIP(hipEventRecord(ev2, e->tail_stream));
+      AF_HIP(hipStreamWaitEvent(stream, ev2, 0));
+    }
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
@@ -975,7 +1199,32 @@ int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_m
     AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
     chain += (double)t;
   }
+  for (auto &pr : e->tail_ms_events) {
+    AF_HIP(hipEventSynchronize(pr.second));
+    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    chain += (double)t;
+  }
   *chain_ms = chain;  // summed over the chain launches of the call (they may overlap suppressor kernels)
+  return AF_OK;
+}
+
+int af_engine_last_chain_launch_ms(af_engine *e, double *first_ms, double *tail_ms, int32_t *segments) {
+  if (!e || !first_ms || !tail_ms) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  *first_ms = *tail_ms = 0.0;
+  if (segments) *segments = (int32_t)e->chain_ms_events.size();
+  if (!e->timing || !e->ev_start || e->last_launches == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  float t = 0.0f;
+  for (auto &pr : e->chain_ms_events) {
+    AF_HIP(hipEventSynchronize(pr.second));
+    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    *first_ms += (double)t;
+  }
+  for (auto &pr : e->tail_ms_events) {
+    AF_HIP(hipEventSynchronize(pr.second));
+    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    *tail_ms += (double)t;
+  }
   return AF_OK;
 }
 

@@ -98,9 +98,18 @@ __device__ __forceinline__ float tp_observe_ring(const float *ring, int n, int l
   return peak;
 }
 
-// kAuto: the compressor's auto-makeup controller and its loudness meter are compiled in
-template <int kRingWaves, int kChunk, bool kAuto>
+// kAuto: the compressor's auto-makeup controller and its loudness meter are compiled in.
+// kMode: 0 = the whole chain in one launch.  1 / 2 = the chain cut in two launches that run on different CUs, a window
+// apart (the chain is issue bound, and a 16-wave workgroup fills a CU's register file, so 4096 streams = 64 workgroups
+// can only ever use 64 CUs per launch):
+//   1 "head": front end, EQ, and the compressor's detector side up to the static gain-reduction target; leaves the
+//             compressor's input in `out` (f32) and the target in `side` (f64, the value the next token consumes);
+//   2 "tail": gain-reduction smoothing, gain, limiter, true-peak limiter / detector, output statistics.
+// Each launch owns (stages and writes back) only the state rows of its own tokens, so head(w+1) and tail(w) may overlap.
+template <int kRingWaves, int kChunk, bool kAuto, int kMode = 0>
 __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchArgs a) {
+  constexpr bool kHead = kMode == 1, kTail = kMode == 2;
+  static_assert(!(kAuto && kMode != 0), "auto-makeup has its own two-launch form");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const ChainParams &P = *a.params;
   const uint32_t flags = P.flags;
@@ -180,12 +189,13 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       L32(kR32NonFinite) = 0.0f;
     }
     // history rows: state row r holds sample n0-32+r
-    for (int r = wave; r < kTpTaps; r += kRingWaves) {
-      const int row = (int)((n0 - kTpTaps + r) & (kTpRing - 1));
-      L32(kR32Tpi + row) = a.st32[(int64_t)(kTpInHist + r) * NS + sc];
-      L32(kR32Tpo + row) = a.st32[(int64_t)(kTpOutHist + r) * NS + sc];
-    }
-    if (flags & kFlagLimiter)
+    if constexpr (!kHead)
+      for (int r = wave; r < kTpTaps; r += kRingWaves) {
+        const int row = (int)((n0 - kTpTaps + r) & (kTpRing - 1));
+        L32(kR32Tpi + row) = a.st32[(int64_t)(kTpInHist + r) * NS + sc];
+        L32(kR32Tpo + row) = a.st32[(int64_t)(kTpOutHist + r) * NS + sc];
+      }
+    if (!kHead && (flags & kFlagLimiter))
       for (int r = wave; r < 2 * W; r += kRingWaves) L32(kR32LimRing + r) = a.st32[(int64_t)(kLimRing + r) * NS + sc];
   }
   __syncthreads();
@@ -236,7 +246,15 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
       }
 
+      double target[kChunk];
+      if constexpr (kTail) {  // the head launch's static gain-reduction targets for this chunk
+        const double *sp = &a.side[(int64_t)s * a.side_stride + t0];
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k) target[k] = (valid && (kFull || k < len)) ? sp[k] : 0.0;
+      }
+
       // =========================== token: input scrub, block input stats, DC block + fixed HP
+      if constexpr (!kTail) {
       token_wait(turn, kTokIn, q);
       {
         double in_sq = first_in_block ? 0.0 : L64(kR64InSq);
@@ -285,9 +303,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
       }
       token_pass(turn, kTokIn, q);
+      }
 
       // =========================== tokens: EQ section groups (eq.rs:371-379, biquad.rs:263-327)
-      for (int g = 0; g < n_groups; ++g) {
+      for (int g = 0; g < (kTail ? 0 : n_groups); ++g) {
         const int k0 = g * kEqGroup;
         const int k1 = (k0 + kEqGroup) < nsec ? (k0 + kEqGroup) : nsec;
         token_wait(turn, kTokEq0 + g, q);
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       // =========================== compressor (compressor.rs:700-774)
       if (flags & kFlagCompressor) {
         const CompressorParams &cp = P.comp;
+        if constexpr (!kTail) {
         double d[kChunk], inst_peak_db[kChunk], rms_db[kChunk], weight_db[kChunk];
         double low_e[kChunk], voiced_e[kChunk], presence_e[kChunk], rms_e[kChunk];
         // ---- token A: side-chain high-pass + band / rms envelopes (linear recurrences)
@@ -467,13 +487,40 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
         token_pass(turn, kTokCompC, q);
         // ---- feed-forward: blended detector level -> static gain-reduction target
-        double target[kChunk];
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) {
             const double blended = 0.6 * db2lin(peak_db[k]) + 0.4 * db2lin(rms_db[k]);
             target[k] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_db[k]);
           }
+        }  // !kTail
+        if constexpr (kHead) {
+          // hand the chunk to the tail launch: compressor input in `out`, targets in `side`
+          if (valid) {
+            double *sp = &a.side[(int64_t)s * a.side_stride + t0];
+  #pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+              if (kFull || k < len) sp[k] = target[k];
+            if (vec_ok && kFull) {
+              float *dst = &a.out[(int64_t)s * a.stream_stride + t0];
+              if constexpr (kChunk == 2) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(x[0], x[1]);
+              } else {
+  #pragma unroll
+                for (int k4 = 0; k4 < kChunk; k4 += 4)
+                  *reinterpret_cast<float4 *>(dst + k4) = make_float4(x[k4], x[k4 + 1], x[k4 + 2], x[k4 + 3]);
+              }
+            } else {
+  #pragma unroll
+              for (int k = 0; k < kChunk; ++k)
+                if (kFull || k < len) {
+                  if (a.layout == 0) a.out[(int64_t)s * a.stream_stride + t0 + k] = x[k];
+                  else a.out[(t0 + k) * a.stream_stride + s] = x[k];
+                }
+            }
+          }
+          return;
+        }
         // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
         double gr_k[kChunk];
         double makeup_lin;
@@ -829,50 +876,55 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
     struct Map { int row, field; };
     // the front-end rows (DC block, 80 Hz high-pass) are written back only by the launch that runs the front end:
     // with the suppressor on they belong to supp_prefilter_kernel, which may already be working on the next window
-    const Map m64[] = {{kR64ScPrevIn, kCompScPrevIn},
-                       {kR64ScPrevOut, kCompScPrevOut}, {kR64LowEnv, kCompLowEnv}, {kR64VoicedEnv, kCompVoicedEnv},
-                       {kR64PresenceEnv, kCompPresenceEnv}, {kR64Plosive, kCompPlosive}, {kR64PeakEnvDb, kCompPeakEnvDb},
-                       {kR64RmsEnvSq, kCompRmsEnvSq}, {kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv},
-                       {kR64SlowEnv, kCompSlowEnv}, {kR64CurReleaseMs, kCompCurReleaseMs},
-                       {kR64TargetReleaseMs, kCompTargetReleaseMs}, {kR64SmoothedMakeup, kCompSmoothedMakeup},
-                       {kR64LimGain, kLimGain}, {kR64ActScore, kCompActivityScore},
-                       {kR64ActReliab, kCompActivityReliability}, {kR64CurrentLufs, kCompCurrentLufs}};
-    const int n_m64 = (int)(sizeof(m64) / sizeof(m64[0]));
-    for (int k = wave; k < n_m64; k += kRingWaves) a.st64[(int64_t)m64[k].field * NS + s] = L64(m64[k].row);
-    for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
-      const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);
-      const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
-      a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + s] = L64(row);
-    }
-    if (wave == 1 % kRingWaves && kAuto && P.comp.meter_slots > 0) {
-      const int mbase = kF64Fixed + 4 * P.n_eq_sections;
-      a.st64[(int64_t)(mbase + kMeterV1) * NS + s] = L64(kR64MeterV1);
-      a.st64[(int64_t)(mbase + kMeterV2) * NS + s] = L64(kR64MeterV2);
-      a.st64[(int64_t)(mbase + kMeterV3) * NS + s] = L64(kR64MeterV3);
-      a.st64[(int64_t)(mbase + kMeterV4) * NS + s] = L64(kR64MeterV4);
-    }
-    if (wave == 0) {
-      const double tau = fmax(L64(kR64CurReleaseMs), 0.001) / 1000.0;  // compressor.rs:760-761
-      a.st64[(int64_t)kCompReleaseCoeff * NS + s] =
-          P.comp.adaptive_release ? exp(-1.0 / (tau * P.comp.sample_rate)) : L64(kR64ReleaseCoeff);
-      if (!(flags & kFlagCompressor)) a.st64[(int64_t)kCompGr * NS + s] = 0.0;
-      if (flags & kFlagDcBlock) {
+    const Map head64[] = {{kR64ScPrevIn, kCompScPrevIn}, {kR64ScPrevOut, kCompScPrevOut}, {kR64LowEnv, kCompLowEnv},
+                          {kR64VoicedEnv, kCompVoicedEnv}, {kR64PresenceEnv, kCompPresenceEnv}, {kR64Plosive, kCompPlosive},
+                          {kR64PeakEnvDb, kCompPeakEnvDb}, {kR64RmsEnvSq, kCompRmsEnvSq}};
+    const Map tail64[] = {{kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv}, {kR64SlowEnv, kCompSlowEnv},
+                          {kR64CurReleaseMs, kCompCurReleaseMs}, {kR64TargetReleaseMs, kCompTargetReleaseMs},
+                          {kR64SmoothedMakeup, kCompSmoothedMakeup}, {kR64LimGain, kLimGain},
+                          {kR64ActScore, kCompActivityScore}, {kR64ActReliab, kCompActivityReliability},
+                          {kR64CurrentLufs, kCompCurrentLufs}};
+    constexpr int n_head64 = (int)(sizeof(head64) / sizeof(head64[0])), n_tail64 = (int)(sizeof(tail64) / sizeof(tail64[0]));
+    if constexpr (!kTail) {  // rows of the tokens up to the gain-reduction target
+      for (int k = wave; k < n_head64; k += kRingWaves) a.st64[(int64_t)head64[k].field * NS + s] = L64(head64[k].row);
+      for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
+        const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);
+        const int row = part < 2 ? kR64Eq + 2 * sec + part : pz_base + 2 * sec + (part - 2);
+        a.st64[(int64_t)(kEqBase + 4 * sec + part) * NS + s] = L64(row);
+      }
+      if (wave == 0 && (flags & kFlagDcBlock)) {
         a.st32[(int64_t)kDcX1 * NS + s] = L32(kR32DcX1);
         a.st32[(int64_t)kDcY1 * NS + s] = L32(kR32DcY1);
         a.st64[(int64_t)kPreZ1 * NS + s] = L64(kR64PreZ1);
         a.st64[(int64_t)kPreZ2 * NS + s] = L64(kR64PreZ2);
       }
-      a.st32[(int64_t)kTpGain * NS + s] = L32(kR32TpGain);
-      a.st32[(int64_t)kLimPrefix * NS + s] = L32(kR32LimPrefix);
     }
-    const int64_t n_end = n0 + a.n_samples;
-    for (int r = wave; r < kTpTaps; r += kRingWaves) {
-      const int rowi = (int)((n_end - kTpTaps + r) & (kTpRing - 1));
-      a.st32[(int64_t)(kTpInHist + r) * NS + s] = L32(kR32Tpi + rowi);
-      a.st32[(int64_t)(kTpOutHist + r) * NS + s] = L32(kR32Tpo + rowi);
+    if constexpr (!kHead) {  // rows of the tokens from the gain-reduction smoothing on
+      for (int k = wave; k < n_tail64; k += kRingWaves) a.st64[(int64_t)tail64[k].field * NS + s] = L64(tail64[k].row);
+      if (wave == 1 % kRingWaves && kAuto && P.comp.meter_slots > 0) {
+        const int mbase = kF64Fixed + 4 * P.n_eq_sections;
+        a.st64[(int64_t)(mbase + kMeterV1) * NS + s] = L64(kR64MeterV1);
+        a.st64[(int64_t)(mbase + kMeterV2) * NS + s] = L64(kR64MeterV2);
+        a.st64[(int64_t)(mbase + kMeterV3) * NS + s] = L64(kR64MeterV3);
+        a.st64[(int64_t)(mbase + kMeterV4) * NS + s] = L64(kR64MeterV4);
+      }
+      if (wave == 0) {
+        const double tau = fmax(L64(kR64CurReleaseMs), 0.001) / 1000.0;  // compressor.rs:760-761
+        a.st64[(int64_t)kCompReleaseCoeff * NS + s] =
+            P.comp.adaptive_release ? exp(-1.0 / (tau * P.comp.sample_rate)) : L64(kR64ReleaseCoeff);
+        if (!(flags & kFlagCompressor)) a.st64[(int64_t)kCompGr * NS + s] = 0.0;
+        a.st32[(int64_t)kTpGain * NS + s] = L32(kR32TpGain);
+        a.st32[(int64_t)kLimPrefix * NS + s] = L32(kR32LimPrefix);
+      }
+      const int64_t n_end = n0 + a.n_samples;
+      for (int r = wave; r < kTpTaps; r += kRingWaves) {
+        const int rowi = (int)((n_end - kTpTaps + r) & (kTpRing - 1));
+        a.st32[(int64_t)(kTpInHist + r) * NS + s] = L32(kR32Tpi + rowi);
+        a.st32[(int64_t)(kTpOutHist + r) * NS + s] = L32(kR32Tpo + rowi);
+      }
+      if (flags & kFlagLimiter)
+        for (int r = wave; r < 2 * W; r += kRingWaves) a.st32[(int64_t)(kLimRing + r) * NS + s] = L32(kR32LimRing + r);
     }
-    if (flags & kFlagLimiter)
-      for (int r = wave; r < 2 * W; r += kRingWaves) a.st32[(int64_t)(kLimRing + r) * NS + s] = L32(kR32LimRing + r);
   }
 #undef L64
 #undef L32
@@ -882,18 +934,26 @@ size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool cross
   return ring_lds_bytes(n_sections, lookahead_samples, crossfade);
 }
 
-template <int kRingWaves, int kChunk, bool kAuto = false>
+template <int kRingWaves, int kChunk, bool kAuto = false, int kMode = 0>
 static hipError_t launch_variant(const LaunchArgs &args, size_t dyn, hipStream_t stream) {
   const int groups = (args.n_streams + kLanes - 1) / kLanes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto, kMode>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) return err;
     attr_set = true;
   }
-  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk, kAuto>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream, args);
+  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk, kAuto, kMode>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream,
+                     args);
   return hipGetLastError();
+}
+
+// The two launches of the split chain (kMode 1 / 2 above); `part` = 1 head, 2 tail.
+hipError_t launch_chain_ring_part(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int part,
+                                  hipStream_t stream) {
+  const size_t dyn = ring_lds_bytes(n_sections, lookahead_samples, crossfade);
+  return part == 1 ? launch_variant<16, 4, false, 1>(args, dyn, stream) : launch_variant<16, 4, false, 2>(args, dyn, stream);
 }
 
 // `variant` = waves * 100 + chunk; 0 picks the default

@@ -28,6 +28,7 @@
 //                          transform, synthesis window.
 //   supp_overlap_kernel    wave per stream, frames in order: overlap-add, /32768, smoothed wet/dry mix.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "af_fft_consts.h"
 #include "af_suppressor.h"
@@ -908,19 +909,6 @@ extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppAr
 // ============================================================================== network
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct RnnLds {
-  float in0[16][kRnnFeatPad];   // features
-  float dense[16][32];
-  float vcat[16][48];           // [dense_out | vad_state] and its r-gated variant
-  float ncat[16][140];          // [dense_out | vad_state | features | noise_state]
-  float dcat[16][212];          // [vad_state | noise_state | features | den_state]
-  float z[16][96], r[16][96];
-  float vad_state[16][24], noise_state[16][48], den_state[16][96];
-  float lastg[16][kRnnBands];
-  float tansig[201];
-  int silence[16];
-};
-
 __device__ __forceinline__ float tansig_approx(const float *table, float x) {
   if (!(x < 8)) return 1;
   if (!(x > -8)) return -1;
@@ -938,206 +926,382 @@ __device__ __forceinline__ float tansig_approx(const float *table, float x) {
 }
 __device__ __forceinline__ float sigmoid_approx(const float *table, float x) { return .5f + .5f * tansig_approx(table, .5f * x); }
 
-// One 16(streams) x 16(units) tile: acc = bias; acc += A[16][K] * W[K][N]  as a k-ordered fmaf chain.  W is the
-// int8 matrix in LDS (exactly the model's weights; the 1/256 scale is applied to the sum as in rnn.c).
-template <int LDA>
-__device__ __forceinline__ v4f mfma_tile(const float (*A)[LDA], const int8_t *W, const float *bias, int k_pad, int n_pad,
-                                         int tile, int lane) {
-  const int col = lane & 15, kq = lane >> 4;
-  const float bv = bias[tile * 16 + col];
-  v4f acc = {bv, bv, bv, bv};
-  const int8_t *wp = W + kq * n_pad + tile * 16 + col;
-#pragma unroll 4
-  for (int k0 = 0; k0 < k_pad; k0 += 4) {
-    const float av = A[col][k0 + kq];           // A[i = lane&15][k = lane>>4]
-    const float wv = (float)wp[k0 * n_pad];     // B[k = lane>>4][j = lane&15]
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc, 0, 0, 0);
-  }
-  return acc;  // acc[reg]: row (stream) = (lane>>4)*4 + reg, column (unit) = tile*16 + (lane&15)
+// The first network kernel gave 16 streams to a 4-wave workgroup: every layer was a handful of tiles spread over
+// the waves, with a barrier before and after (14 per frame) and copies to build each layer's concatenated input.
+// A frame is a strictly dependent chain, so that kernel's duration was the sum of those latencies (matrix cores
+// busy 5 %); and with 90 KB of weights + 56 KB of activations in LDS a workgroup needed a CU to itself, so beside
+// the other suppressor kernels its workgroups mostly waited for a CU to drain.  Here ONE wave owns 16 streams for
+// the whole window, needs 26 KB of LDS and never meets a workgroup barrier inside the frame loop:
+//   * the recurrent states live in registers in the matrix-core result layout (row = stream, column = unit), so z,
+//     the state, and the candidate h of a GRU unit meet in the same lane without touching LDS;
+//   * the layer inputs are two LDS rows per stream laid out so that every concatenation the model needs is a
+//     contiguous slice:  r1 = [dense | vad | features | noise]  (vad GRU reads r1[0:48], noise GRU all of it),
+//     r2 = [vad | noise | features | denoise]  (denoise GRU; the output layer reads r2[114:210]);
+//   * the int8 weights stream from L2 (90 KB in all, shared by every wave on the chip) as one dword per lane per
+//     four k-steps (`w4` layout below), fetched three groups = 12 k-steps ahead of their use;
+//   * several independent accumulator chains (tiles of one gate) run through one pass over K, sharing each A
+//     operand, so the 44-cycle dependent latency of v_mfma_f32_16x16x4_f32 is hidden;
+//   * the next frame's features are fetched while the current frame computes.
+// Arithmetic per (stream, unit) is the same k-ordered fmaf chain from the bias as before: results are unchanged
+// bit for bit (tools/ab_suppressor.py).
+constexpr int kR1 = 140, kR2 = 212;
+constexpr int kR1Vad = 24, kR1Feat = 48, kR1Noise = 90;   // r1 = [dense 24 | vad 24 | features 42 | noise 48 | 0 0]
+constexpr int kR2Noise = 24, kR2Feat = 72, kR2Den = 114;  // r2 = [vad 24 | noise 48 | features 42 | denoise 96 | 0 0]
+constexpr int kRnnBiasTiles = 37;  // dense 2 | vad z r h 2 each | noise z r h 3 each | denoise z r h 6 each | out 2
+constexpr int kRnnTablePad = 208;
+constexpr int kW4Ahead = 3;        // weight groups in flight ahead of the one being consumed
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this keeps the compiler from moving them across and waits
+  // for the writes to land before other lanes of the same wave read them
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
-extern "C" __global__ __launch_bounds__(256) void supp_rnn_kernel(SuppArgs a, RnnDeviceWeights w) {
-  __shared__ RnnLds L;
-  extern __shared__ __attribute__((aligned(16))) int8_t w8[];  // all eleven matrices, staged once per workgroup
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < w.w8_bytes / 16; i += 256)
-    reinterpret_cast<uint4 *>(w8)[i] = reinterpret_cast<const uint4 *>(w.w8)[i];
-  const int s0 = blockIdx.x * 16;
-  const float kScale = 1.f / 256;
-  for (int i = tid; i < 201; i += 256) L.tansig[i] = w.tansig[i];
-  for (int i = tid; i < 16 * (24 + 48 + 96 + kRnnBands); i += 256) {
-    const int row = i / (24 + 48 + 96 + kRnnBands), c = i % (24 + 48 + 96 + kRnnBands);
-    const int s = s0 + row < a.n_streams ? s0 + row : a.n_streams - 1;
-    const float *st = a.state + (int64_t)s * SuppState::kCount;
-    if (c < 24) L.vad_state[row][c] = st[SuppState::kVadState + c];
-    else if (c < 72) L.noise_state[row][c - 24] = st[SuppState::kNoiseState + c - 24];
-    else if (c < 168) L.den_state[row][c - 72] = st[SuppState::kDenoiseState + c - 72];
-    else L.lastg[row][c - 168] = st[SuppState::kLastG + c - 168];
+// NC chains (tiles 0 .. NC - 1 of matrix MATRIX) through its K.  Weights come through a buffer descriptor over the
+// whole w4 blob: address = descriptor base + lane * 4 (the one VGPR) + a compile-time scalar offset, so no load needs
+// a pointer of its own (with flat addresses the compiler kept ~450 loop-invariant 64-bit pointers alive and spilled).
+template <int NC, int MATRIX>
+__device__ __forceinline__ void mfma_chains(const float *ap, __amdgpu_buffer_rsrc_t wsrc, unsigned lane4, v4f (&acc)[NC]) {
+  constexpr int K_PAD = kRnnMatrixDims[MATRIX].k_pad, TILES = kRnnMatrixDims[MATRIX].n_pad / 16;
+  static_assert(NC == TILES, "one chain per 16-unit tile");
+  constexpr int kSteps = K_PAD / 4, kGroups = (kSteps + 3) / 4;
+  constexpr int kBase = w4_matrix_offset(MATRIX);
+  uint32_t wbuf[kW4Ahead][NC];
+#pragma unroll
+  for (int p = 0; p < kW4Ahead; ++p)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      wbuf[p][c] = p < kGroups ? __builtin_amdgcn_raw_buffer_load_b32(wsrc, lane4, (kBase + (p * TILES + c) * 64) * 4, 0) : 0u;
+  float av = ap[0];  // A[stream = lane & 15][k0 + (lane >> 4)], fetched one step ahead of its use
+#pragma unroll
+  for (int g = 0; g < kGroups; ++g) {
+    uint32_t cur[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cur[c] = wbuf[g % kW4Ahead][c];
+    if (g + kW4Ahead < kGroups) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        wbuf[g % kW4Ahead][c] =
+            __builtin_amdgcn_raw_buffer_load_b32(wsrc, lane4, (kBase + ((g + kW4Ahead) * TILES + c) * 64) * 4, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int step = g * 4 + j;
+      if (step < kSteps) {
+        const float av_next = ap[(step + 1 < kSteps ? step + 1 : step) * 4];
+        __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of this step's matrix operations
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float wv = (float)(int)(int8_t)(cur[c] >> (8 * j));
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wv, acc[c], 0, 0, 0);
+        }
+        av = av_next;
+      }
+    }
   }
-  __syncthreads();
+}
+
+size_t rnn_lds_bytes(int waves) {
+  return (kRnnTablePad + kRnnBiasTiles * 16) * sizeof(float) + (size_t)waves * 16 * (kR1 + kR2 + 32) * sizeof(float);
+}
+
+template <int NC>
+__device__ __forceinline__ void load_bias(v4f (&acc)[NC], const float *bias, int first_bias_tile, int col) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float bv = bias[(first_bias_tile + c) * 16 + col];
+    acc[c] = v4f{bv, bv, bv, bv};
+  }
+}
+
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves, 2) void supp_rnn_kernel(SuppArgs a, RnnDeviceWeights w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rnn_lds[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const unsigned lane = tid & 63;
+  float *tansig = reinterpret_cast<float *>(rnn_lds);
+  float *bias = tansig + kRnnTablePad;
+  float *act = bias + kRnnBiasTiles * 16 + wave * (16 * (kR1 + kR2 + 32));
+  float(*r1)[kR1] = reinterpret_cast<float(*)[kR1]>(act);
+  float(*r2)[kR2] = reinterpret_cast<float(*)[kR2]>(act + 16 * kR1);
+  float(*lastg)[32] = reinterpret_cast<float(*)[32]>(act + 16 * (kR1 + kR2));
+
+  for (int i = tid; i < 201; i += 64 * kWaves) tansig[i] = w.tansig[i];
+  for (int i = tid; i < kRnnBiasTiles * 16; i += 64 * kWaves) {
+    const int t = i >> 4, c = i & 15;
+    const float *src;
+    int tt;
+    if (t < 2) { src = w.dense_b; tt = t; }
+    else if (t < 8) { src = w.vad_b[(t - 2) / 2]; tt = (t - 2) % 2; }
+    else if (t < 17) { src = w.noise_b[(t - 8) / 3]; tt = (t - 8) % 3; }
+    else if (t < 35) { src = w.den_b[(t - 17) / 6]; tt = (t - 17) % 6; }
+    else { src = w.out_b; tt = t - 35; }
+    bias[i] = src[tt * 16 + c];
+  }
+  __syncthreads();  // the only workgroup barrier: table and biases are in place
+
+  const int s0 = (blockIdx.x * kWaves + wave) * 16;
+  if (s0 >= a.n_streams) return;
   const int col = lane & 15, rq = lane >> 4;
+  const float kScale = 1.f / 256;
+  const int NS = a.n_streams;
+
+  // ---- recurrent state in registers: element [r] of tile t belongs to stream rq*4 + r, unit t*16 + col
+  float st_vad[2][4], st_noise[3][4], st_den[6][4];
+  int srow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int s = s0 + rq * 4 + r;
+    srow[r] = s < NS ? s : NS - 1;
+    const float *st = a.state + (int64_t)srow[r] * SuppState::kCount;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int unit = t * 16 + col;
+      st_vad[t][r] = unit < 24 ? st[SuppState::kVadState + unit] : 0.0f;
+      lastg[rq * 4 + r][unit] = unit < kRnnBands ? st[SuppState::kLastG + unit] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) st_noise[t][r] = st[SuppState::kNoiseState + t * 16 + col];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) st_den[t][r] = st[SuppState::kDenoiseState + t * 16 + col];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rq * 4 + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int unit = t * 16 + col;
+      if (unit < 24) {
+        r1[row][unit] = 0.0f;
+        r1[row][kR1Vad + unit] = st_vad[t][r];
+        r2[row][unit] = st_vad[t][r];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      r1[row][kR1Noise + t * 16 + col] = st_noise[t][r];
+      r2[row][kR2Noise + t * 16 + col] = st_noise[t][r];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) r2[row][kR2Den + t * 16 + col] = st_den[t][r];
+  }
+  if (lane < 16) {
+    r1[lane][138] = r1[lane][139] = 0.0f;
+    r2[lane][210] = r2[lane][211] = 0.0f;
+  }
+
+  // ---- features of a frame: 16 streams x 42 values, element i = lane + 64 j
+  constexpr int kFeatPerLane = (16 * kRnnFeat + 63) / 64;  // 11
+  float pf[kFeatPerLane];
+  int psil[4];
+  auto fetch = [&](int f) {
+#pragma unroll
+    for (int j = 0; j < kFeatPerLane; ++j) {
+      const int i = lane + 64 * j;
+      const int row = i / kRnnFeat, c = i - row * kRnnFeat;
+      pf[j] = 0.0f;
+      if (row < 16) {
+        const int s = s0 + row < NS ? s0 + row : NS - 1;
+        pf[j] = a.rec[(int64_t)f * NS + s].feat[c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) psil[r] = a.rec[(int64_t)f * NS + srow[r]].silence;
+  };
+  if (a.n_frames > 0) fetch(0);
+
+  const float *a_dense = &r1[col][kR1Feat + rq];
+  const float *a_r1 = &r1[col][rq];
+  const float *a_r2 = &r2[col][rq];
+  const float *a_out = &r2[col][kR2Den + rq];
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(w.w4), 0, w4_matrix_offset(11) * 4, 0x00020000);
+  const unsigned lane4 = lane * 4;
 
   for (int f = 0; f < a.n_frames; ++f) {
-    // ---- stage the 16 feature vectors
-    for (int i = tid; i < 16 * kRnnFeatPad; i += 256) {
-      const int row = i / kRnnFeatPad, c = i % kRnnFeatPad;
-      const int s = s0 + row < a.n_streams ? s0 + row : a.n_streams - 1;
-      const SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
-      L.in0[row][c] = c < kRnnFeat ? rec->feat[c] : 0.0f;
-      if (c == 0) L.silence[row] = rec->silence;
-    }
-    __syncthreads();
-    // ---- input_dense 42 -> 24 (tanh): 2 tiles on waves 0,1
-    if (wave < 2) {
-      const v4f acc = mfma_tile<kRnnFeatPad>(L.in0, w8 + w.off8[0], w.dense_b, kDimDense.k_pad, kDimDense.n_pad, wave, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = wave * 16 + col;
-        if (unit < 24) L.dense[row][unit] = tansig_approx(L.tansig, kScale * acc[r]);
+    int sil[4];
+#pragma unroll
+    for (int j = 0; j < kFeatPerLane; ++j) {
+      const int i = lane + 64 * j;
+      const int row = i / kRnnFeat, c = i - row * kRnnFeat;
+      if (row < 16) {
+        r1[row][kR1Feat + c] = pf[j];
+        r2[row][kR2Feat + c] = pf[j];
       }
     }
-    __syncthreads();
-    // ---- vad GRU (24 in, 24 units)
-    for (int i = tid; i < 16 * 48; i += 256) {
-      const int row = i / 48, c = i % 48;
-      L.vcat[row][c] = c < 24 ? L.dense[row][c] : L.vad_state[row][c - 24];
-    }
-    __syncthreads();
-    {  // z, r: 2 gates x 2 tiles = 4 tiles, one per wave
-      const int gate = wave >> 1, tile = wave & 1;
-      const v4f acc = mfma_tile<48>(L.vcat, w8 + w.off8[1 + gate], w.vad_b[gate], kDimVad.k_pad, kDimVad.n_pad, tile, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = tile * 16 + col;
-        if (unit < 24) (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * 24; i += 256) {
-      const int row = i / 24, c = i % 24;
-      L.vcat[row][24 + c] = L.vad_state[row][c] * L.r[row][c];
-    }
-    __syncthreads();
-    if (wave < 2) {
-      const v4f acc = mfma_tile<48>(L.vcat, w8 + w.off8[3], w.vad_b[2], kDimVad.k_pad, kDimVad.n_pad, wave, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = wave * 16 + col;
-        if (unit < 24) {
-          float sum = kScale * acc[r];
-          sum = sum < 0 ? 0 : sum;
-          const float zz = L.z[row][unit];
-          const float h = zz * L.vad_state[row][unit] + (1 - zz) * sum;
-          if (!L.silence[row]) L.vad_state[row][unit] = h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sil[r] = psil[r];
+    wave_lds_fence();
+    if (f + 1 < a.n_frames) fetch(f + 1);
+
+    // ---- input_dense 42 -> 24 (tanh).  K runs over r1[48:92]: the two columns past the features hold noise-state
+    // values, which meet the zero rows of the padded weight matrix
+    {
+      v4f acc[2];
+      load_bias(acc, bias, 0, col);
+      mfma_chains<2, 0>(a_dense, wsrc, lane4, acc);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = c * 16 + col;
+          if (unit < 24) r1[rq * 4 + r][unit] = tansig_approx(tansig, kScale * acc[c][r]);
         }
-      }
     }
-    __syncthreads();
-    // ---- noise GRU (90 in, 48 units)
-    for (int i = tid; i < 16 * 140; i += 256) {
-      const int row = i / 140, c = i % 140;
-      float v = 0.0f;
-      if (c < 24) v = L.dense[row][c];
-      else if (c < 48) v = L.vad_state[row][c - 24];
-      else if (c < 90) v = L.in0[row][c - 48];
-      else if (c < 138) v = L.noise_state[row][c - 90];
-      L.ncat[row][c] = v;
-    }
-    __syncthreads();
-    for (int t = wave; t < 6; t += 4) {  // z, r: 2 gates x 3 tiles
-      const int gate = t / 3, tile = t % 3;
-      const v4f acc = mfma_tile<140>(L.ncat, w8 + w.off8[4 + gate], w.noise_b[gate], kDimNoise.k_pad, kDimNoise.n_pad, tile, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = tile * 16 + col;
-        (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * 48; i += 256) {
-      const int row = i / 48, c = i % 48;
-      L.ncat[row][90 + c] = L.noise_state[row][c] * L.r[row][c];
-    }
-    __syncthreads();
-    if (wave < 3) {
-      const v4f acc = mfma_tile<140>(L.ncat, w8 + w.off8[6], w.noise_b[2], kDimNoise.k_pad, kDimNoise.n_pad, wave, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = wave * 16 + col;
-        float sum = kScale * acc[r];
-        sum = sum < 0 ? 0 : sum;
-        const float zz = L.z[row][unit];
-        const float h = zz * L.noise_state[row][unit] + (1 - zz) * sum;
-        if (!L.silence[row]) L.noise_state[row][unit] = h;
-      }
-    }
-    __syncthreads();
-    // ---- denoise GRU (114 in, 96 units)
-    for (int i = tid; i < 16 * 212; i += 256) {
-      const int row = i / 212, c = i % 212;
-      float v = 0.0f;
-      if (c < 24) v = L.vad_state[row][c];
-      else if (c < 72) v = L.noise_state[row][c - 24];
-      else if (c < 114) v = L.in0[row][c - 72];
-      else if (c < 210) v = L.den_state[row][c - 114];
-      L.dcat[row][c] = v;
-    }
-    __syncthreads();
-    for (int t = wave; t < 12; t += 4) {  // z, r: 2 gates x 6 tiles
-      const int gate = t / 6, tile = t % 6;
-      const v4f acc = mfma_tile<212>(L.dcat, w8 + w.off8[7 + gate], w.den_b[gate], kDimDenoise.k_pad, kDimDenoise.n_pad, tile, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = tile * 16 + col;
-        (gate == 0 ? L.z : L.r)[row][unit] = sigmoid_approx(L.tansig, kScale * acc[r]);
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * 96; i += 256) {
-      const int row = i / 96, c = i % 96;
-      L.dcat[row][114 + c] = L.den_state[row][c] * L.r[row][c];
-    }
-    __syncthreads();
-    for (int t = wave; t < 6; t += 4) {
-      const v4f acc = mfma_tile<212>(L.dcat, w8 + w.off8[9], w.den_b[2], kDimDenoise.k_pad, kDimDenoise.n_pad, t, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = t * 16 + col;
-        float sum = kScale * acc[r];
-        sum = sum < 0 ? 0 : sum;
-        const float zz = L.z[row][unit];
-        const float h = zz * L.den_state[row][unit] + (1 - zz) * sum;
-        // every tile reads only the OLD state through dcat, so committing here is safe
-        if (!L.silence[row]) L.z[row][unit] = h;  // stage the new state in z, commit after the barrier
-        else L.z[row][unit] = L.den_state[row][unit];
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * 96; i += 256) L.den_state[i / 96][i % 96] = L.z[i / 96][i % 96];
-    __syncthreads();
-    // ---- denoise_output 96 -> 22 (sigmoid), then g = max(g, 0.6 lastg)
-    if (wave < 2) {
-      const v4f acc = mfma_tile<96>(L.den_state, w8 + w.off8[10], w.out_b, kDimOut.k_pad, kDimOut.n_pad, wave, lane);
-      for (int r = 0; r < 4; ++r) {
-        const int row = rq * 4 + r, unit = wave * 16 + col;
-        if (unit < kRnnBands && s0 + row < a.n_streams) {
-          SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s0 + row);
-          if (!L.silence[row]) {
-            float gv = sigmoid_approx(L.tansig, kScale * acc[r]);
-            rec->gains_raw[unit] = gv;
-            gv = fmaxf(gv, 0.6f * L.lastg[row][unit]);
-            L.lastg[row][unit] = gv;
-            rec->gains[unit] = gv;
-          } else {
-            rec->gains[unit] = 1.0f;
-            rec->gains_raw[unit] = 1.0f;
+    wave_lds_fence();
+
+    // ---- vad GRU (24 in, 24 units) over r1[0:48]
+    {
+      float z[2][4];
+      v4f acc[2];
+      load_bias(acc, bias, 2, col);
+      mfma_chains<2, 1>(a_r1, wsrc, lane4, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = sigmoid_approx(tansig, kScale * acc[t][r]);
+      load_bias(acc, bias, 4, col);
+      mfma_chains<2, 2>(a_r1, wsrc, lane4, acc);
+      wave_lds_fence();  // every z / r chain has read the old state: its slots may hold the r-gated state now
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t * 16 + col < 24) r1[rq * 4 + r][kR1Vad + t * 16 + col] = st_vad[t][r] * sigmoid_approx(tansig, kScale * acc[t][r]);
+      wave_lds_fence();
+      load_bias(acc, bias, 6, col);
+      mfma_chains<2, 3>(a_r1, wsrc, lane4, acc);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = kScale * acc[t][r];
+          sum = sum < 0 ? 0 : sum;
+          const float h = z[t][r] * st_vad[t][r] + (1 - z[t][r]) * sum;
+          if (!sil[r]) st_vad[t][r] = h;
+          if (t * 16 + col < 24) {
+            r1[rq * 4 + r][kR1Vad + t * 16 + col] = st_vad[t][r];
+            r2[rq * 4 + r][t * 16 + col] = st_vad[t][r];
           }
         }
-      }
+      wave_lds_fence();
     }
-    __syncthreads();
+
+    // ---- noise GRU (90 in, 48 units) over all of r1
+    {
+      float z[3][4];
+      v4f acc[3];
+      load_bias(acc, bias, 8, col);
+      mfma_chains<3, 4>(a_r1, wsrc, lane4, acc);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = sigmoid_approx(tansig, kScale * acc[t][r]);
+      load_bias(acc, bias, 11, col);
+      mfma_chains<3, 5>(a_r1, wsrc, lane4, acc);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          r1[rq * 4 + r][kR1Noise + t * 16 + col] = st_noise[t][r] * sigmoid_approx(tansig, kScale * acc[t][r]);
+      wave_lds_fence();
+      load_bias(acc, bias, 14, col);
+      mfma_chains<3, 6>(a_r1, wsrc, lane4, acc);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = kScale * acc[t][r];
+          sum = sum < 0 ? 0 : sum;
+          const float h = z[t][r] * st_noise[t][r] + (1 - z[t][r]) * sum;
+          if (!sil[r]) st_noise[t][r] = h;
+          r1[rq * 4 + r][kR1Noise + t * 16 + col] = st_noise[t][r];
+          r2[rq * 4 + r][kR2Noise + t * 16 + col] = st_noise[t][r];
+        }
+      wave_lds_fence();
+    }
+
+    // ---- denoise GRU (114 in, 96 units) over all of r2: z (six chains), then r (six chains), then h
+    {
+      float z[6][4];
+      v4f acc[6];
+      load_bias(acc, bias, 17, col);
+      mfma_chains<6, 7>(a_r2, wsrc, lane4, acc);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[t][r] = sigmoid_approx(tansig, kScale * acc[t][r]);
+      load_bias(acc, bias, 23, col);
+      mfma_chains<6, 8>(a_r2, wsrc, lane4, acc);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          r2[rq * 4 + r][kR2Den + t * 16 + col] = st_den[t][r] * sigmoid_approx(tansig, kScale * acc[t][r]);
+      wave_lds_fence();
+      load_bias(acc, bias, 29, col);
+      mfma_chains<6, 9>(a_r2, wsrc, lane4, acc);
+      wave_lds_fence();
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sum = kScale * acc[t][r];
+          sum = sum < 0 ? 0 : sum;
+          const float h = z[t][r] * st_den[t][r] + (1 - z[t][r]) * sum;
+          if (!sil[r]) st_den[t][r] = h;
+          r2[rq * 4 + r][kR2Den + t * 16 + col] = st_den[t][r];
+        }
+      wave_lds_fence();
+    }
+
+    // ---- denoise_output 96 -> 22 (sigmoid) over r2[114:210], then g = max(g, 0.6 lastg)
+    {
+      v4f acc[2];
+      load_bias(acc, bias, 35, col);
+      mfma_chains<2, 10>(a_out, wsrc, lane4, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = t * 16 + col, s = s0 + rq * 4 + r;
+          if (unit < kRnnBands && s < NS) {
+            SuppFrameRec *rec = a.rec + ((int64_t)f * NS + s);
+            if (!sil[r]) {
+              float gv = sigmoid_approx(tansig, kScale * acc[t][r]);
+              rec->gains_raw[unit] = gv;
+              gv = fmaxf(gv, 0.6f * lastg[rq * 4 + r][unit]);
+              lastg[rq * 4 + r][unit] = gv;  // only this lane ever touches the slot
+              rec->gains[unit] = gv;
+            } else {
+              rec->gains[unit] = 1.0f;
+              rec->gains_raw[unit] = 1.0f;
+            }
+          }
+        }
+    }
   }
-  for (int i = tid; i < 16 * (24 + 48 + 96 + kRnnBands); i += 256) {
-    const int row = i / (24 + 48 + 96 + kRnnBands), c = i % (24 + 48 + 96 + kRnnBands);
-    if (s0 + row >= a.n_streams) continue;
-    float *st = a.state + (int64_t)(s0 + row) * SuppState::kCount;
-    if (c < 24) st[SuppState::kVadState + c] = L.vad_state[row][c];
-    else if (c < 72) st[SuppState::kNoiseState + c - 24] = L.noise_state[row][c - 24];
-    else if (c < 168) st[SuppState::kDenoiseState + c - 72] = L.den_state[row][c - 72];
-    else st[SuppState::kLastG + c - 168] = L.lastg[row][c - 168];
+
+  // ---- state back to HBM
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int s = s0 + rq * 4 + r;
+    if (s >= NS) continue;
+    float *st = a.state + (int64_t)s * SuppState::kCount;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int unit = t * 16 + col;
+      if (unit < 24) st[SuppState::kVadState + unit] = st_vad[t][r];
+      if (unit < kRnnBands) st[SuppState::kLastG + unit] = lastg[rq * 4 + r][unit];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) st[SuppState::kNoiseState + t * 16 + col] = st_noise[t][r];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) st[SuppState::kDenoiseState + t * 16 + col] = st_den[t][r];
   }
 }
 
@@ -1283,26 +1447,50 @@ hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
 }
 
 // Analysis of one window: spectra, then pitch + cepstral features (frames in order per stream).
-hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream) {
+// `before_pitch` (optional) is waited on between the spectra and the pitch search: the pitch search is 50 one-wave
+// workgroups per stream with a small footprint, and while its grid drains, kernels with larger workgroups (the network:
+// 256 VGPRs per wave) are not dispatched at all -- so the caller orders it after the previous window's network launch.
+hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream, hipEvent_t before_pitch) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
+  if (before_pitch) {
+    hipError_t err = hipStreamWaitEvent(stream, before_pitch, 0);
+    if (err != hipSuccess) return err;
+  }
   hipLaunchKernelGGL(supp_pitchsearch_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
   return hipGetLastError();
 }
 
 // The rest of the window: pitch-aligned spectra, the network, resynthesis, overlap-add.
-hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream) {
+// `after_network` (optional) is recorded right behind the network launch (see launch_suppressor_analysis).
+hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
+                                       hipEvent_t after_network) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   {
+    // AF_RNN_VARIANT = waves (16 streams each) per workgroup: 1, 2 or 4.  Measured on one box, full bench step:
+    // 4 -> 287-290 ms, 1 -> 298 ms (the round's first network kernel, a 4-wave workgroup per 16 streams: 301 ms)
+    static const int variant = [] {
+      const char *env = std::getenv("AF_RNN_VARIANT");
+      return env ? std::atoi(env) : 4;
+    }();
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(supp_rnn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(supp_rnn_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (err != hipSuccess) return err;
       attr_set = true;
     }
-    hipLaunchKernelGGL(supp_rnn_kernel, dim3((a.n_streams + 15) / 16), dim3(256), (size_t)w.w8_bytes, stream, a, w);
+    const unsigned groups = (unsigned)((a.n_streams + 15) / 16);
+    switch (variant) {
+      case 1: hipLaunchKernelGGL(supp_rnn_kernel<1>, dim3(groups), dim3(64), rnn_lds_bytes(1), stream, a, w); break;
+      case 2: hipLaunchKernelGGL(supp_rnn_kernel<2>, dim3((groups + 1) / 2), dim3(128), rnn_lds_bytes(2), stream, a, w); break;
+      default: hipLaunchKernelGGL(supp_rnn_kernel<4>, dim3((groups + 3) / 4), dim3(256), rnn_lds_bytes(4), stream, a, w); break;
+    }
+  }
+  if (after_network) {
+    hipError_t err = hipEventRecord(after_network, stream);
+    if (err != hipSuccess) return err;
   }
   hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);

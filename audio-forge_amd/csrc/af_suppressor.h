@@ -55,6 +55,18 @@ constexpr RnnLayerDims kDimNoise{90, 48, 140, 48, 48};
 constexpr RnnLayerDims kDimDenoise{114, 96, 212, 96, 96};
 constexpr RnnLayerDims kDimOut{96, 0, 96, 22, 32};
 
+// the eleven matrices in blob order: dense, vad z r h, noise z r h, denoise z r h, out
+constexpr RnnLayerDims kRnnMatrixDims[11] = {kDimDense, kDimVad, kDimVad, kDimVad, kDimNoise, kDimNoise, kDimNoise,
+                                             kDimDenoise, kDimDenoise, kDimDenoise, kDimOut};
+// "w4" operand order of the wave-private network kernel: dword [group g][tile][lane] of a matrix holds
+// W[16 g + 4 j + (lane >> 4)][16 tile + (lane & 15)] in byte j (k beyond k_pad: zero); offsets in dwords
+constexpr int w4_matrix_dwords(int i) { return ((kRnnMatrixDims[i].k_pad / 4 + 3) / 4) * (kRnnMatrixDims[i].n_pad / 16) * 64; }
+constexpr int w4_matrix_offset(int i) {
+  int o = 0;
+  for (int j = 0; j < i; ++j) o += w4_matrix_dwords(j);
+  return o;
+}
+
 struct RnnDeviceWeights {
   const float *dense_w, *dense_b;           // [44][32], [32]
   const float *vad_w[3], *vad_b[3];         // [48][32]
@@ -62,11 +74,9 @@ struct RnnDeviceWeights {
   const float *den_w[3], *den_b[3];         // [212][96]
   const float *out_w, *out_b;               // [96][32]
   const float *tansig;                      // [201]
-  // the same eleven matrices as int8 (the model's native precision), [K_pad][N_pad] each, one 16-byte-aligned blob:
-  // the network kernel keeps them in LDS (90 KB) so that no step of its frame-to-frame chain waits on L2
-  const int8_t *w8;
-  int32_t off8[11];                         // dense, vad z r h, noise z r h, denoise z r h, out
-  int32_t w8_bytes;
+  // the same eleven matrices as int8 (the model's native precision) in the operand order of the network kernel,
+  // which streams them from L2 (w4_matrix_offset / w4_matrix_dwords above)
+  const uint32_t *w4;
 };
 
 struct SuppTables {

@@ -11,8 +11,9 @@
 
 namespace af {
 
-hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream);
-hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream);
+hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream, hipEvent_t before_pitch);
+hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
+                                       hipEvent_t after_network);
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
 
 // int8 network weights in the layout of the public RNNoise model (dense: [in][out]; GRU: [in][3*units],
@@ -71,7 +72,7 @@ struct SuppressorHost {
   bool weights_dirty = true;
   // device side
   float *d_blob = nullptr;   // all f32 matrices + tables, one allocation
-  int8_t *d_w8 = nullptr;    // the matrices again as int8 (what the network kernel stages into LDS)
+  uint32_t *d_w4 = nullptr;  // the matrices as int8 in the network kernel's operand order (af_suppressor.h)
   size_t blob_floats = 0;
   RnnDeviceWeights dw{};
   SuppTables tables{};
@@ -179,25 +180,42 @@ struct SuppressorHost {
       dw.den_w[g] = d_blob + ew[g];
       dw.den_b[g] = d_blob + eb[g];
     }
-    {  // int8 copies of the eleven matrices, same padded layout (every entry of the f32 blob is a small integer)
+    {  // the eleven matrices back as int8 (every entry of the f32 blob is a small integer), same padded layout
       const size_t offs[11] = {dw_off, vw[0], vw[1], vw[2], nw[0], nw[1], nw[2], ew[0], ew[1], ew[2], ow_off};
       const RnnLayerDims dims[11] = {kDimDense, kDimVad, kDimVad, kDimVad, kDimNoise, kDimNoise, kDimNoise,
                                      kDimDenoise, kDimDenoise, kDimDenoise, kDimOut};
       std::vector<int8_t> w8;
+      int32_t off8[11];
       for (int i = 0; i < 11; ++i) {
-        dw.off8[i] = (int32_t)w8.size();
+        off8[i] = (int32_t)w8.size();
         const size_t count = (size_t)dims[i].k_pad * dims[i].n_pad;
         for (size_t j = 0; j < count; ++j) w8.push_back((int8_t)blob[offs[i] + j]);
         while (w8.size() % 16) w8.push_back(0);
       }
-      dw.w8_bytes = (int32_t)w8.size();
-      if (!d_w8) {
-        hipError_t e8 = hipMalloc(&d_w8, w8.size());
-        if (e8 != hipSuccess) return e8;
+      // ... re-ordered for the network kernel (af_suppressor.h): k padded to whole groups of 16 with zero weights
+      std::vector<uint32_t> w4;
+      for (int i = 0; i < 11; ++i) {
+        if ((int)w4.size() != w4_matrix_offset(i)) return hipErrorInvalidValue;
+        const int n_pad = dims[i].n_pad, tiles = n_pad / 16, groups = (dims[i].k_pad / 4 + 3) / 4;
+        for (int g = 0; g < groups; ++g)
+          for (int t = 0; t < tiles; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+              uint32_t word = 0;
+              for (int j = 0; j < 4; ++j) {
+                const int k = 16 * g + 4 * j + (lane >> 4), n = 16 * t + (lane & 15);
+                const int8_t v = k < dims[i].k_pad ? w8[(size_t)off8[i] + (size_t)k * n_pad + n] : (int8_t)0;
+                word |= (uint32_t)(uint8_t)v << (8 * j);
+              }
+              w4.push_back(word);
+            }
       }
-      hipError_t e8 = hipMemcpy(d_w8, w8.data(), w8.size(), hipMemcpyHostToDevice);
-      if (e8 != hipSuccess) return e8;
-      dw.w8 = d_w8;
+      if (!d_w4) {
+        hipError_t e4 = hipMalloc(&d_w4, w4.size() * sizeof(uint32_t));
+        if (e4 != hipSuccess) return e4;
+      }
+      hipError_t e4 = hipMemcpy(d_w4, w4.data(), w4.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+      if (e4 != hipSuccess) return e4;
+      dw.w4 = d_w4;
     }
     dw.tansig = d_blob + tansig_off;
     tables.half_window = d_blob + win_off;
@@ -255,8 +273,8 @@ struct SuppressorHost {
   void release_all() {
     release_workspace();
     (void)hipFree(d_blob);
-    (void)hipFree(d_w8);
-    d_w8 = nullptr;
+    (void)hipFree(d_w4);
+    d_w4 = nullptr;
     (void)hipFree(d_state);
     d_blob = d_state = nullptr;
     blob_floats = 0;

@@ -208,7 +208,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms, supp_ms, chain_ms = [], [], []
+    kernel_ms, supp_ms, chain_ms, first_ms, tail_ms, segments = [], [], [], [], [], 1
     sm, cm = C.c_double(0.0), C.c_double(0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -217,6 +217,9 @@ def main() -> None:
         engine._lib.af_engine_last_stage_ms(engine._h, C.byref(sm), C.byref(cm))
         supp_ms.append(sm.value)
         chain_ms.append(cm.value)
+        f_ms, t_ms, segments = engine.last_chain_launch_ms()
+        first_ms.append(f_ms)
+        tail_ms.append(t_ms)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -231,13 +234,15 @@ def main() -> None:
     used = int(engine._lib.af_engine_last_kernel(engine._h))
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
     quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
-    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
+    split = float(np.mean(tail_ms)) > 0.0  # the chain ran as head + tail launches (af_ring_kernel.hip, kMode 1 / 2)
+    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}{',head' if split else ''}>",
+                   3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on this stream)
         # (with the suppressor on the chain runs once per 50-frame window, so a step holds several launches)
-        window = int(os.environ.get("AF_SUPP_WINDOW_FRAMES", "50")) * 480
-        launches = max(1, n // window) if full and n % window == 0 else 1
-        avg_kernel_s = float(np.mean(chain_ms)) / 1000.0 / launches
+        # (split chain: the dominant kernel is the head launch; the tail's launches are reported beside it)
+        launches = max(1, int(segments))
+        avg_kernel_s = float(np.mean(first_ms)) / 1000.0 / launches
         frames_per_launch = streams * n // launches
         achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         line = {
@@ -268,6 +273,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, streams, n // launches),
                 "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
+                "tail_kernel_ms": float(np.mean(tail_ms)) / launches if split else None,
             },
             "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),
                          "all_kernels": float(np.mean(kernel_ms))},

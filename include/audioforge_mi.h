@@ -212,10 +212,14 @@ int64_t af_engine_samples_processed(const af_engine *e);
  * when the batch alone cannot fill the chip, AF_KERNEL_PHASED (64 streams per workgroup) otherwise and whenever
  * auto-makeup or the EQ-before-de-esser order need its pre-pass mode */
 int af_engine_set_kernel(af_engine *e, int32_t kernel);
-/* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
- * (built: 16x4, 16x2, 12x4, 12x2, 8x4, 8x2; 0,0 = default) */
+/* The token-ring chain can run each suppressor window as two launches on different CUs (head: front end, EQ,
+ * compressor detector; tail: gain smoothing, limiter, true peak).  Results are bit-identical to the one-launch form;
+ * it is off by default because both halves turn out bound by their longest token, not by issue slots. */
+int af_engine_set_chain_split(af_engine *e, int32_t on);
 /* AF_KERNEL_* the most recent chain launch used; VALUE, not a status */
 int af_engine_last_kernel(const af_engine *e);
+/* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
+ * (built: 16x4, 16x2, 12x4, 12x2, 8x4, 8x2; 0,0 = default) */
 int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk);
 /* HIP-event timing of the kernels launched by the last process call, in milliseconds,
  * measured on the stream the kernels ran on (0 when timing is disabled) */
@@ -223,6 +227,9 @@ int af_engine_set_timing_enabled(af_engine *e, int32_t enabled);
 int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches);
 /* the same split at the suppressor | chain boundary (front-end pre-pass counts as suppressor time) */
 int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_ms);
+/* chain launches of the last call: summed duration of the whole-chain (or split-chain head) launches, of the split
+ * chain's tail launches (0 when the chain ran as one launch per segment), and the number of segments */
+int af_engine_last_chain_launch_ms(af_engine *e, double *first_ms, double *tail_ms, int32_t *segments);
 
 /* ---- product resampler ------------------------------------------------------------------
  * `build_sinc_resampler_with_quality` + `simulate_product_resampler`

@@ -115,3 +115,43 @@ def test_frame_multiple_is_required(mi):
     with pytest.raises(ValueError, match="multiple of 480"):
         eng.process(np.zeros((1, 500), dtype=np.float32))
     eng.close()
+
+
+def test_split_chain_is_bit_identical_to_one_launch(mi):
+    """The two-launch form of the token-ring chain (head: EQ + compressor detector, tail: gain smoothing + limiter +
+    true peak, af_ring_kernel.hip kMode 1 / 2) against the one-launch form on the same engine configuration: audio and
+    every block row bit for bit, across two calls (state hand-over) and a ragged stream group."""
+    from mic_eq_mi import mic_eq_core as core
+
+    audio = S.batch_signal(70, 180)  # 70 streams (64 + 6), 1.8 s: windows of 50 frames + a 30-frame tail
+    settings = S.limiter_settings(2.0)
+    bands = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]
+
+    def run(split: int):
+        eng = core.Engine(48_000.0, audio.shape[0])
+        core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)  # legacy setters: a 72-sample crossfade is pending
+        eng.set_prefilter_enabled(1, 1)
+        eng.set_suppressor_enabled(1)
+        eng.set_chain_split(split)
+        a = eng.process(audio[:, : 110 * 480])
+        rows_a = eng.block_stats().copy()
+        b = eng.process(audio[:, 110 * 480 :])
+        rows_b = eng.block_stats().copy()
+        eng.close()
+        return np.concatenate([a, b], axis=1), rows_a, rows_b
+
+    y1, ra1, rb1 = run(1)
+    y0, ra0, rb0 = run(0)
+    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+    assert ra1.tobytes() == ra0.tobytes()
+    assert rb1.tobytes() == rb0.tobytes()
+    assert float(np.abs(y1).max()) > 0.05
+
+
+def test_ramped_window_schedule_matches_restatement(mi, oracle):
+    """A call long enough for the ramped window schedule (windows of 4, 8, 16, 32, 50 ..., 32, 16, 8, 4 frames,
+    af_api.cpp) must give what frame-by-frame processing gives: the windows are an execution detail."""
+    audio = S.batch_signal(18, 260)  # 2.6 s: 4+8+16+32 | 50 50 40 | 32+16+8+4
+    want = np.stack([oracle.suppressor_process(audio[s], 1.0, 0x5EED) for s in range(audio.shape[0])])
+    got = mi.suppress(audio, 1.0, 0x5EED)
+    _check(got, want)
