@@ -77,22 +77,24 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
     return out
 
 
-def pmc_traffic(kernel_name: str, streams: int, samples_per_launch: int):
+def pmc_traffic(kernel_name: str, streams: int, samples_per_launch: float):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 correction applied; profiles/README.md), when that profile was taken
-    at this launch shape; None otherwise (counters cannot be read from inside this script)."""
+    WRITE_SIZE collected separately, gfx950 correction applied; profiles/README.md).  The passes were taken with uniform
+    windows (AF_SUPP_RAMP=0: every chain launch covers `samples_per_launch` of the profile's launch shape); the chain's
+    traffic is proportional to the samples a launch covers, so the figure is scaled to this run's average launch.
+    None when the profile was taken at another batch size (counters cannot be read from inside this script)."""
     path = ROOT / "profiles" / "r01_pmc_traffic.json"
     try:
         prof = json.loads(path.read_text())
     except (OSError, ValueError):
         return None
     shape = prof.get("launch_shape", {})
-    if shape.get("streams") != streams or shape.get("samples_per_launch") != samples_per_launch:
+    if shape.get("streams") != streams or not shape.get("samples_per_launch"):
         return None
     base = kernel_name.split("<")[0]
     for name, row in prof.get("kernels", {}).items():
         if base in name and row.get("traffic_bytes_per_launch"):
-            return float(row["traffic_bytes_per_launch"])
+            return float(row["traffic_bytes_per_launch"]) * samples_per_launch / float(shape["samples_per_launch"])
     return None
 
 
@@ -270,7 +272,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, streams, n // launches),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, streams, n / launches),
                 "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
                 "tail_kernel_ms": float(np.mean(tail_ms)) / launches if split else None,
