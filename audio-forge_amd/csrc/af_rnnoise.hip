@@ -468,36 +468,59 @@ struct PitchLds {
   float dist[kCepsMem][kCepsMem];
 };
 
-// find_best_pitch (pitch.c) over precomputed numerators / energy deltas; every lane walks the same recurrence
-__device__ __forceinline__ void best_pitch_scan(const float *numa, const float *da, float Syy, int mp, int &bp0, int &bp1) {
+// find_best_pitch (pitch.c) over precomputed numerators / energy deltas, in two phases that together reproduce the
+// sequential scan exactly:
+//   1. the window-energy recurrence Syy <- max(1, Syy + da[i]) is walked in order (two dependent operations per lag;
+//      every lane computes the same values and leaves Syy[i] in `syy`);
+//   2. the running best two candidates only change at lags that pass `num * best_den[1] > best_num[1] * Syy`, so 64
+//      lags are tested at once against the current pair, the FIRST passing lag is applied the way the sequential scan
+//      would, and only the lags after it are tested again: every lag meets exactly the state the sequential scan
+//      would have shown it.  (The first form walked all lags one at a time on every lane: ~35 instructions per lag,
+//      441 lags per frame, most of this kernel's instructions.)
+template <int MP>
+__device__ __forceinline__ void best_pitch_scan(const float *numa, const float *da, float *syy, float Syy, int lane, int &bp0,
+                                                int &bp1) {
+#pragma unroll 8
+  for (int i = 0; i < MP; ++i) {
+    syy[i] = Syy;  // same address, same value from every lane
+    Syy = fmaxf(1.0f, Syy + da[i]);
+  }
+  __syncthreads();
   float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
   bp0 = 0;
   bp1 = 1;
-#pragma unroll 4
-  for (int i = 0; i < mp; ++i) {
-    const float num = numa[i];
-    if (num >= 0.0f) {
-      if (num * bd1 > bn1 * Syy) {
-        if (num * bd0 > bn0 * Syy) {
-          bn1 = bn0; bd1 = bd0; bp1 = bp0;
-          bn0 = num; bd0 = Syy; bp0 = i;
-        } else {
-          bn1 = num; bd1 = Syy; bp1 = i;
-        }
+#pragma unroll
+  for (int base = 0; base < MP; base += 64) {
+    const int i = base + lane;
+    const float num = i < MP ? numa[i] : -1.0f;
+    const float sy = i < MP ? syy[i] : 1.0f;
+    unsigned long long todo = ~0ull;  // lanes whose lag comes after the last applied one
+    for (;;) {
+      const bool pass = num >= 0.0f && num * bd1 > bn1 * sy;
+      const unsigned long long m = __ballot(pass) & todo;
+      if (m == 0) break;
+      const int k = __ffsll((long long)m) - 1;
+      const float nk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(num), k));
+      const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), k));
+      if (nk * bd0 > bn0 * sk) {
+        bn1 = bn0; bd1 = bd0; bp1 = bp0;
+        bn0 = nk; bd0 = sk; bp0 = base + k;
+      } else {
+        bn1 = nk; bd1 = sk; bp1 = base + k;
       }
+      todo = k == 63 ? 0ull : ~0ull << (k + 1);
     }
-    Syy += da[i];
-    Syy = fmaxf(1.0f, Syy);
   }
 }
 
 // ---- pitch, part 1: everything that depends on the frame alone (wave per (frame, stream), fully parallel):
 // 2x decimation + LPC-4 whitening, coarse and fine cross-correlation search.  Leaves the whitened buffer and
 // the candidate period for part 2.
-struct PitchSearchLds {
+struct alignas(16) PitchSearchLds {
   float ds[kPitchBuf / 2];
   float xc[304];
   float numa[304], da[304];
+  float syy[304];
 };
 extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(SuppArgs a, SuppTables tb) {
   __shared__ PitchSearchLds L;
@@ -574,7 +597,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
     int best0, best1;
     {
       // coarse: 4x decimated, 147 lags x 240 products (lane per lag, left-to-right order)
-      const int len = kRnnWindow >> 2, mp = max_pitch >> 2;
+      constexpr int len = kRnnWindow >> 2, mp = (kPitchMax - 3 * kPitchMin) >> 2;
       {
         // the three lag rounds (lane, lane + 64, lane + 128) share every x-value: one loop, three running sums
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -602,12 +625,13 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
       }
       const float Syy0 = 1.0f + wave_dot64_sq_stride2(L.ds, len, lane);
       __syncthreads();
-      best_pitch_scan(L.numa, L.da, Syy0, mp, best0, best1);
+      static_assert(mp == 147, "coarse lag count");
+      best_pitch_scan<mp>(L.numa, L.da, L.syy, Syy0, lane, best0, best1);
     }
     __syncthreads();
     {
       // fine: 2x decimated, only within +-2 of the two coarse candidates (at most ten lags)
-      const int len = kRnnWindow >> 1, mp = max_pitch >> 1;
+      constexpr int len = kRnnWindow >> 1, mp = (kPitchMax - 3 * kPitchMin) >> 1;
       for (int i = lane; i < mp; i += 64) {
         L.xc[i] = 0.0f;
         L.numa[i] = -1.0f;
@@ -633,7 +657,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
       }
       const float Syy0 = 1.0f + wave_dot64(L.ds, L.ds, len, lane);
       __syncthreads();
-      best_pitch_scan(L.numa, L.da, Syy0, mp, best0, best1);
+      best_pitch_scan<mp>(L.numa, L.da, L.syy, Syy0, lane, best0, best1);
     }
     int pitch_index;
     {
