@@ -23,6 +23,9 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
+bool tp_detect_supported(int control_block, int64_t n_samples);
+hipError_t launch_tp_detect(const float *audio, float *st32, BlockStats *stats, int64_t stream_stride, int64_t n_samples,
+                            int32_t n_streams, int32_t control_block, hipStream_t stream);
 hipError_t launch_chain_ring_part(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int part,
                                   hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
@@ -78,6 +81,7 @@ struct af_engine {
   int kernel = AF_KERNEL_AUTO;
   int ring_variant = 0;
   bool chain_split = false;  // two-launch form of the token-ring chain (measured slower: DESIGN.md 4.2c)
+  bool detector_kernel = false;  // output-side true-peak detector as its own kernel (measured slower: DESIGN.md 4.2d)
   bool timing = false;
   int64_t samples_processed = 0;
   int64_t last_blocks = 0;
@@ -102,6 +106,7 @@ struct af_engine {
   int64_t side_capacity = 0;               // doubles per buffer
   hipStream_t tail_stream = nullptr;       // split chain: the tail launches
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
+  hipStream_t post_stream = nullptr;       // the output-side true-peak detector of each finished chain window (af_truepeak.hip)
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tail_ms_events;  // timing brackets of the tail launches of the last call
   af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
@@ -312,8 +317,12 @@ void advance_crossfades(af_engine *e, int64_t n) {
 // `params_stream` is where parameter uploads are ordered; `stream` is where the kernels run.
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
-                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/) {
+                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/,
+                         bool *detector_left_out = nullptr) {
+  // `detector_left_out`: the caller can run the output-side TruePeakDetector as a kernel of its own behind this launch
+  // (af_truepeak.hip); set to true when this launch left it out
   af::ChainParams run = run_in;
+  if (detector_left_out) *detector_left_out = false;
   const int cb = run.control_block;
   const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
   bool any_xf = false;
@@ -431,6 +440,10 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, auto_makeup, stream));
       e->last_launches += 2;
     } else {
+      if (detector_left_out && !deesser && layout == AF_LAYOUT_STREAM_MAJOR && af::tp_detect_supported(cb, n_samples)) {
+        run.flags |= af::kFlagNoOutDetector;
+        *detector_left_out = true;
+      }
       if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
         e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
         AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
@@ -610,7 +623,8 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = nullptr;
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = nullptr;
+  if (e->post_stream) (void)hipStreamDestroy(e->post_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
   if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
   for (double *p : e->d_side)
@@ -808,6 +822,11 @@ int af_engine_set_chain_split(af_engine *e, int32_t on) {
   e->chain_split = on != 0;
   return AF_OK;
 }
+int af_engine_set_detector_kernel(af_engine *e, int32_t on) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  e->detector_kernel = on != 0;
+  return AF_OK;
+}
 int af_engine_last_kernel(const af_engine *e) { return e ? e->last_kernel_used : 0; }
 int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
@@ -935,7 +954,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = stream;
+    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = stream;
     e->borrowed_streams = true;
   }
   const bool split = chain_split_eligible(e, run);
@@ -963,9 +982,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->post_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->post_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -977,6 +997,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
+  if (!e->post_stream) AF_HIP(hipStreamCreateWithFlags(&e->post_stream, hipStreamNonBlocking));
+  static const int detector_env = [] {  // AF_TP_DETECT_KERNEL=0/1 overrides the engine's setting (A/B runs)
+    const char *env = std::getenv("AF_TP_DETECT_KERNEL");
+    return env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
+  }();
+  const bool separate_detector = detector_env >= 0 ? detector_env != 0 : e->detector_kernel;
+  bool post_used = false;
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
   if (split && !e->tail_stream) {
     if (e->partition_chain_cus > 0) {  // the tail shares the chain's CUs (reserve twice the workgroup count for a split chain)
@@ -1009,6 +1036,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(e->ana_stream, ev, 0));
     if (split) AF_HIP(hipStreamWaitEvent(e->tail_stream, ev, 0));
     if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
+    if (e->post_stream != stream) AF_HIP(hipStreamWaitEvent(e->post_stream, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
@@ -1103,8 +1131,21 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
                               e->d_stats + blocks_done * e->n_streams, w, e->aux_stream, e->tail_stream, head_done[w],
                               tail_done[w], w >= 2 ? tail_done[w - 2] : nullptr);
     } else {
+      bool left_out = false;
       rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
-                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream);
+                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream,
+                                separate_detector ? &left_out : nullptr);
+      if (rc) return rc;
+      if (left_out) {  // the window's output-side true-peak detector, behind its chain launch, on the suppressor's CUs
+        hipEvent_t chain_done;
+        if (int rc2 = next_event(&chain_done)) return rc2;
+        AF_HIP(hipEventRecord(chain_done, e->aux_stream));
+        AF_HIP(hipStreamWaitEvent(e->post_stream, chain_done, 0));
+        AF_HIP(af::launch_tp_detect(out + seg0, e->d_st32, e->d_stats + blocks_done * e->n_streams, stream_stride, seg_n,
+                                    e->n_streams, cb, e->post_stream));
+        e->last_launches += 2;
+        post_used = true;
+      }
     }
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
@@ -1123,6 +1164,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (int rc = next_event(&ev2)) return rc;
       AF_HIP(hipEventRecord(ev2, e->tail_stream));
       AF_HIP(hipStreamWaitEvent(stream, ev2, 0));
+    }
+    if (post_used && e->post_stream != stream) {
+      hipEvent_t ev3;
+      if (int rc = next_event(&ev3)) return rc;
+      AF_HIP(hipEventRecord(ev3, e->post_stream));
+      AF_HIP(hipStreamWaitEvent(stream, ev3, 0));
     }
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));

@@ -99,6 +99,7 @@ enum ChainFlags : uint32_t {
   kFlagPrePass = 1u << 9,      // first of two launches: front end + EQ only, no detector, no compressor bookkeeping
   kFlagSplitHead = 1u << 10,   // split chain, first launch: up to the compressor's static gain-reduction target
   kFlagSplitTail = 1u << 11,   // split chain, second launch: from the gain-reduction smoothing on
+  kFlagNoOutDetector = 1u << 12,  // the output-side TruePeakDetector runs as a kernel of its own (af_truepeak.hip)
 };
 
 struct ChainParams {

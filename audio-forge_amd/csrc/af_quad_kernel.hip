@@ -77,6 +77,8 @@ __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
       }
     }
   }
+  // (raising the wave's priority inside a serial unit, which gains 7 % in the ring kernel, costs 2 % here: with four
+  // samples across a quad the serial units are a larger share of every wave's work)
 }
 __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
   __hip_atomic_store(&turn_base[tok], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -66,6 +66,7 @@ __host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, 
 // host reports the launch as failed instead of the GPU hanging.
 constexpr int kAbortSlot = 32;
 __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
+  __builtin_amdgcn_sched_barrier(0);
   int spins = 0;
   while (__hip_atomic_load(&turn_base[tok], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != q) {
     __builtin_amdgcn_s_sleep(1);
@@ -77,9 +78,16 @@ __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
       }
     }
   }
+  // a wave inside a serial unit is on the workgroup's critical path: it issues ahead of the three feed-forward waves
+  // that share its SIMD (measured: 257 -> 240 ms of chain time per bench step)
+  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_sched_barrier(0);  // nothing that could have run before the wait is scheduled into the serial unit
 }
 __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
+  __builtin_amdgcn_sched_barrier(0);  // ... and nothing that can wait until after the hand-over delays it
   __hip_atomic_store(&turn_base[tok], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Bandlimited4xPeak::observe (true_peak.rs:173-186) over a shared ring: sample n sits in row n & 127
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 #define L64(row) l64[(row)*kLanes + lane]
 #define L32(row) l32[(row)*kLanes + lane]
 
+  const bool out_detector = !(flags & (kFlagPrePass | kFlagNoOutDetector));  // this launch runs the output-side detector
   const int tid = threadIdx.x;
   const int lane = tid & (kLanes - 1);
   const int wave = tid / kLanes;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       for (int r = wave; r < kTpTaps; r += kRingWaves) {
         const int row = (int)((n0 - kTpTaps + r) & (kTpRing - 1));
         L32(kR32Tpi + row) = a.st32[(int64_t)(kTpInHist + r) * NS + sc];
-        L32(kR32Tpo + row) = a.st32[(int64_t)(kTpOutHist + r) * NS + sc];
+        L32(kR32Tpo + row) = out_detector ? a.st32[(int64_t)(kTpOutHist + r) * NS + sc] : 0.0f;
       }
     if (!kHead && (flags & kFlagLimiter))
       for (int r = wave; r < 2 * W; r += kRingWaves) L32(kR32LimRing + r) = a.st32[(int64_t)(kLimRing + r) * NS + sc];
@@ -800,7 +809,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
               det = 0.0f;  // TruePeakDetector::process_block, true_peak.rs:212
             }
             out_peak = fmaxf(out_peak, fabsf(o));
-            if (!(flags & kFlagPrePass)) L32(kR32Tpo + ((nb + k) & (kTpRing - 1))) = det;
+            if (out_detector) L32(kR32Tpo + ((nb + k) & (kTpRing - 1))) = det;
           }
         L64(kR64OutSq) = out_sq;
         L32(kR32OutPeak) = out_peak;
@@ -838,19 +847,21 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
           }
       }
       float otp = 0.0f;
-      if (!(flags & kFlagPrePass)) {
+      if (out_detector) {
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
       }
       // ---- token: fold the chunk's output true peak into the block maximum
-      token_wait(turn, kTokFin, q);
-      {
-        const float m = fmaxf(first_in_block ? 0.0f : L32(kR32OutTp), otp);
-        L32(kR32OutTp) = m;
-        if (last_in_block && valid && row) row->output_true_peak = m;
+      if (out_detector) {
+        token_wait(turn, kTokFin, q);
+        {
+          const float m = fmaxf(first_in_block ? 0.0f : L32(kR32OutTp), otp);
+          L32(kR32OutTp) = m;
+          if (last_in_block && valid && row) row->output_true_peak = m;
+        }
+        token_pass(turn, kTokFin, q);
       }
-      token_pass(turn, kTokFin, q);
     };
     if (len == kChunk) chunk_body(std::true_type{});
     else chunk_body(std::false_type{});
@@ -920,7 +931,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       for (int r = wave; r < kTpTaps; r += kRingWaves) {
         const int rowi = (int)((n_end - kTpTaps + r) & (kTpRing - 1));
         a.st32[(int64_t)(kTpInHist + r) * NS + s] = L32(kR32Tpi + rowi);
-        a.st32[(int64_t)(kTpOutHist + r) * NS + s] = L32(kR32Tpo + rowi);
+        if (out_detector) a.st32[(int64_t)(kTpOutHist + r) * NS + s] = L32(kR32Tpo + rowi);
       }
       if (flags & kFlagLimiter)
         for (int r = wave; r < 2 * W; r += kRingWaves) a.st32[(int64_t)(kLimRing + r) * NS + s] = L32(kR32LimRing + r);

@@ -216,6 +216,10 @@ int af_engine_set_kernel(af_engine *e, int32_t kernel);
  * compressor detector; tail: gain smoothing, limiter, true peak).  Results are bit-identical to the one-launch form;
  * it is off by default because both halves turn out bound by their longest token, not by issue slots. */
 int af_engine_set_chain_split(af_engine *e, int32_t on);
+/* With the suppressor on, the output-side TruePeakDetector (block_processor.rs:159) can run as a matrix-core kernel of
+ * its own behind each chain window instead of inside the chain kernel: same block rows bit for bit, off by default
+ * (the chain kernel turned out bound by its serial units, not by the detector's instructions). */
+int af_engine_set_detector_kernel(af_engine *e, int32_t on);
 /* AF_KERNEL_* the most recent chain launch used; VALUE, not a status */
 int af_engine_last_kernel(const af_engine *e);
 /* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
