@@ -65,8 +65,16 @@ __host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, 
 // (seconds) the workgroup-wide abort word is raised, every later wait falls through, and the
 // host reports the launch as failed instead of the GPU hanging.
 constexpr int kAbortSlot = 32;
+#ifdef AF_TOKEN_PROFILE  // development aid (make EXTRA=-DAF_TOKEN_PROFILE): cycles every serial unit is waited for / held,
+                         // printed by workgroup 0 at the end of each launch
+__shared__ unsigned g_prof[2][16][12];
+__shared__ long long g_prof_acq[16];
+#endif
 __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
   __builtin_amdgcn_sched_barrier(0);
+#ifdef AF_TOKEN_PROFILE
+  const long long prof_t0 = clock64();
+#endif
   int spins = 0;
   while (__hip_atomic_load(&turn_base[tok], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != q) {
     __builtin_amdgcn_s_sleep(1);
@@ -81,10 +89,20 @@ __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
   // a wave inside a serial unit is on the workgroup's critical path: it issues ahead of the three feed-forward waves
   // that share its SIMD (measured: 257 -> 240 ms of chain time per bench step)
   __builtin_amdgcn_s_setprio(3);
+#ifdef AF_TOKEN_PROFILE
+  if ((threadIdx.x & 63) == 0) {
+    const long long t1 = clock64();
+    g_prof[0][threadIdx.x >> 6][tok] += (unsigned)(t1 - prof_t0);
+    g_prof_acq[threadIdx.x >> 6] = t1;
+  }
+#endif
   __builtin_amdgcn_sched_barrier(0);  // nothing that could have run before the wait is scheduled into the serial unit
 }
 __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
   __builtin_amdgcn_sched_barrier(0);  // ... and nothing that can wait until after the hand-over delays it
+#ifdef AF_TOKEN_PROFILE
+  if ((threadIdx.x & 63) == 0) g_prof[1][threadIdx.x >> 6][tok] += (unsigned)(clock64() - g_prof_acq[threadIdx.x >> 6]);
+#endif
   __hip_atomic_store(&turn_base[tok], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
@@ -148,6 +166,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 
   // ---------------- stage the per-stream state into LDS (wave w takes rows w, w+16, ...)
   if (tid < 64) turn[tid] = 0;
+#ifdef AF_TOKEN_PROFILE
+  for (int i = tid; i < 2 * 16 * 12; i += kRingWaves * kLanes) (&g_prof[0][0][0])[i] = 0;
+  const long long prof_k0 = clock64();
+#endif
   {
     struct Map { int row, field; };
     const Map m64[] = {{kR64PreZ1, kPreZ1}, {kR64PreZ2, kPreZ2}, {kR64ScPrevIn, kCompScPrevIn},
@@ -730,8 +752,22 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
               const double peak = (double)fmaxf(sfx, prefix);
               ring[j * kLanes + lane] = xin;
               if (j + 1 == W) {
+                // suffix maxima of the block just completed, eight at a time: the loads of a batch are issued together (as one
+                // load -> max -> store per element the compiler must assume `suf` aliases `ring` and pays an LDS round trip per
+                // element, W of them inside the serial unit every W samples)
                 float m = 0.0f;
-                for (int kk = W - 1; kk >= 0; --kk) {
+                int kk = W - 1;
+                for (; kk >= 7; kk -= 8) {
+                  float v[8];
+  #pragma unroll
+                  for (int u = 0; u < 8; ++u) v[u] = fabsf(ring[(kk - u) * kLanes + lane]);
+  #pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    m = fmaxf(m, v[u]);
+                    suf[(kk - u) * kLanes + lane] = m;
+                  }
+                }
+                for (; kk >= 0; --kk) {
                   m = fmaxf(m, fabsf(ring[kk * kLanes + lane]));
                   suf[kk * kLanes + lane] = m;
                 }
@@ -868,6 +904,17 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   }
   __syncthreads();
   if (tid == 0 && turn[kAbortSlot] != 0 && a.status) atomicExch(a.status, 1);
+#ifdef AF_TOKEN_PROFILE
+  if (tid == 0 && blockIdx.x == 0 && Q > 0) {
+    printf("ring profile: %lld chunks, kernel %lld ticks = %.1f per chunk\n", (long long)Q, (long long)(clock64() - prof_k0),
+           (double)(clock64() - prof_k0) / (double)Q);
+    for (int t = 0; t < kTokEq0 + n_groups; ++t) {
+      long long w = 0, h = 0;
+      for (int k = 0; k < kRingWaves; ++k) { w += g_prof[0][k][t]; h += g_prof[1][k][t]; }
+      printf("  token %2d: held %.1f ticks per chunk, waited for %.1f\n", t, (double)h / (double)Q, (double)w / (double)Q);
+    }
+  }
+#endif
 
   // ---------------- write the state back
   if (valid && (flags & kFlagPrePass)) {
@@ -945,13 +992,18 @@ size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool cross
   return ring_lds_bytes(n_sections, lookahead_samples, crossfade);
 }
 
+#ifdef AF_TOKEN_PROFILE
+constexpr int kRingMaxDynamicLds = 160 * 1024 - 4096;  // the profile's static arrays come out of the same 160 KB
+#else
+constexpr int kRingMaxDynamicLds = 160 * 1024;
+#endif
 template <int kRingWaves, int kChunk, bool kAuto = false, int kMode = 0>
 static hipError_t launch_variant(const LaunchArgs &args, size_t dyn, hipStream_t stream) {
   const int groups = (args.n_streams + kLanes - 1) / kLanes;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto, kMode>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRingMaxDynamicLds);
     if (err != hipSuccess) return err;
     attr_set = true;
   }
