@@ -129,7 +129,7 @@ struct af_engine {
   hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
   std::vector<hipEvent_t> sync_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
-  int supp_window_frames = 50;
+  int supp_window_frames = 30;  // measured 12..80: 30 -> 253 ms per bench step, 50 -> 257, 20 -> 258, 80 -> 267 (AF_SUPP_WINDOW_FRAMES)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
   af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}

@@ -60,7 +60,7 @@ def test_batch_of_streams_and_state_across_calls(mi, oracle):
     eng.set_limiter_enabled(0)
     eng.set_suppressor_enabled(1)
     eng.set_control_block_samples(480)
-    a = eng.process(audio[:, : 70 * 480])   # two calls, windows of 50 frames inside each
+    a = eng.process(audio[:, : 70 * 480])   # two calls, several windows inside each
     b = eng.process(audio[:, 70 * 480 :])
     eng.close()
     got = np.concatenate([a, b], axis=1)
@@ -123,7 +123,7 @@ def test_split_chain_is_bit_identical_to_one_launch(mi):
     every block row bit for bit, across two calls (state hand-over) and a ragged stream group."""
     from mic_eq_mi import mic_eq_core as core
 
-    audio = S.batch_signal(70, 180)  # 70 streams (64 + 6), 1.8 s: windows of 50 frames + a 30-frame tail
+    audio = S.batch_signal(70, 180)  # 70 streams (64 + 6), 1.8 s: several windows per call
     settings = S.limiter_settings(2.0)
     bands = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]
 
@@ -149,9 +149,9 @@ def test_split_chain_is_bit_identical_to_one_launch(mi):
 
 
 def test_ramped_window_schedule_matches_restatement(mi, oracle):
-    """A call long enough for the ramped window schedule (windows of 4, 8, 16, 32, 50 ..., 32, 16, 8, 4 frames,
+    """A call long enough for the ramped window schedule (windows of 4, 8, 16, 30 ..., 16, 8, 4 frames,
     af_api.cpp) must give what frame-by-frame processing gives: the windows are an execution detail."""
-    audio = S.batch_signal(18, 260)  # 2.6 s: 4+8+16+32 | 50 50 40 | 32+16+8+4
+    audio = S.batch_signal(18, 260)  # 2.6 s: 4+8+16 | 30 x 6, 24 | 16+8+4
     want = np.stack([oracle.suppressor_process(audio[s], 1.0, 0x5EED) for s in range(audio.shape[0])])
     got = mi.suppress(audio, 1.0, 0x5EED)
     _check(got, want)
