@@ -106,6 +106,7 @@ struct af_engine {
   int64_t side_capacity = 0;               // doubles per buffer
   hipStream_t tail_stream = nullptr;       // split chain: the tail launches
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
+  hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
   hipStream_t post_stream = nullptr;       // the output-side true-peak detector of each finished chain window (af_truepeak.hip)
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> tail_ms_events;  // timing brackets of the tail launches of the last call
@@ -129,7 +130,7 @@ struct af_engine {
   hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
   std::vector<hipEvent_t> sync_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
-  int supp_window_frames = 30;  // measured 12..80: 30 -> 253 ms per bench step, 50 -> 257, 20 -> 258, 80 -> 267 (AF_SUPP_WINDOW_FRAMES)
+  int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
   af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}
@@ -623,7 +624,8 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = nullptr;
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = e->fin_stream = nullptr;
+  if (e->fin_stream) (void)hipStreamDestroy(e->fin_stream);
   if (e->post_stream) (void)hipStreamDestroy(e->post_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
   if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
@@ -954,7 +956,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = stream;
+    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = e->fin_stream = stream;
     e->borrowed_streams = true;
   }
   const bool split = chain_split_eligible(e, run);
@@ -983,9 +985,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->post_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->post_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->post_stream, &e->fin_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -998,6 +1001,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
   if (!e->post_stream) AF_HIP(hipStreamCreateWithFlags(&e->post_stream, hipStreamNonBlocking));
+  if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
+  static const bool split_synthesis = [] {  // AF_SYNTH_SPLIT=0: resynthesis + overlap-add stay behind the network on one stream
+    const char *env = std::getenv("AF_SYNTH_SPLIT");
+    return !env || std::atoi(env) != 0;
+  }();
+  const hipStream_t fin = split_synthesis ? e->fin_stream : nullptr;
   static const int detector_env = [] {  // AF_TP_DETECT_KERNEL=0/1 overrides the engine's setting (A/B runs)
     const char *env = std::getenv("AF_TP_DETECT_KERNEL");
     return env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
@@ -1037,6 +1046,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (split) AF_HIP(hipStreamWaitEvent(e->tail_stream, ev, 0));
     if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
     if (e->post_stream != stream) AF_HIP(hipStreamWaitEvent(e->post_stream, ev, 0));
+    if (fin && fin != stream) AF_HIP(hipStreamWaitEvent(fin, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
@@ -1045,7 +1055,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     sa.out = out;
     sa.xh = e->supp.d_xh + (size_t)(index % kXh) * e->supp.xh_floats;
     sa.X = e->supp.d_X + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
-    sa.P = e->supp.d_P;
+    sa.P = e->supp.d_P + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
     sa.ds = e->supp.d_ds;
     sa.rec = e->supp.d_rec + (size_t)(index & 1) * e->supp.ws_cells;
     sa.state = e->supp.d_state;
@@ -1112,8 +1122,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   for (int64_t w = 0; w < n_windows; ++w) {
     const int64_t f0 = win_f0[w], nf = win_nf[w];
     AF_HIP(hipStreamWaitEvent(syn, ana_done[w], 0));
-    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w]));
-    AF_HIP(hipEventRecord(syn_done[w], syn));
+    if (fin && fin != syn && w >= 2) AF_HIP(hipStreamWaitEvent(syn, syn_done[w - 2], 0));  // its pitch-spectrum buffer is free
+    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w], fin));
+    AF_HIP(hipEventRecord(syn_done[w], (fin && fin != syn) ? fin : syn));
     e->last_launches += 7;
     if (w + 2 < n_windows)
       if (int rc = enqueue_pre(w + 2)) return rc;
@@ -1152,7 +1163,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
     blocks_done += (seg_n + cb - 1) / cb;
   }
-  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, syn));  // last suppressor kernel done
+  if (e->timing) AF_HIP(hipEventRecord(e->ev_mid, (fin && fin != syn) ? fin : syn));  // last suppressor kernel done
   if (syn != stream && n_windows > 0) AF_HIP(hipStreamWaitEvent(stream, syn_done[n_windows - 1], 0));
   {
     hipEvent_t ev;

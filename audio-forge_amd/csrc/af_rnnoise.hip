@@ -1488,8 +1488,10 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
 
 // The rest of the window: pitch-aligned spectra, the network, resynthesis, overlap-add.
 // `after_network` (optional) is recorded right behind the network launch (see launch_suppressor_analysis).
+// `finish_stream` (optional, needs `after_network`): resynthesis and overlap-add run there, so that the next window's
+// pitch spectra and network launch can start while they run.
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
-                                       hipEvent_t after_network) {
+                                       hipEvent_t after_network, hipStream_t finish_stream) {
   const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
   {
@@ -1516,8 +1518,14 @@ hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, 
     hipError_t err = hipEventRecord(after_network, stream);
     if (err != hipSuccess) return err;
   }
-  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
-  hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, stream, a);
+  hipStream_t fin = stream;
+  if (finish_stream && finish_stream != stream && after_network) {
+    hipError_t err = hipStreamWaitEvent(finish_stream, after_network, 0);
+    if (err != hipSuccess) return err;
+    fin = finish_stream;
+  }
+  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, fin, a, tb);
+  hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, fin, a);
   return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ namespace af {
 
 hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream, hipEvent_t before_pitch);
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
-                                       hipEvent_t after_network);
+                                       hipEvent_t after_network, hipStream_t finish_stream);
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
 
 // int8 network weights in the layout of the public RNNoise model (dense: [in][out]; GRU: [in][3*units],
@@ -246,12 +246,13 @@ struct SuppressorHost {
     const size_t cells = (size_t)frames * n_streams;
     // The windows of a call run as a pipeline (pre-pass | analysis | synthesis), so the buffers that cross a
     // stage boundary exist several times: the model input lives from the pre-pass to the synthesis (3 windows
-    // in flight), spectra and frame records from the analysis to the synthesis (2).
+    // in flight), spectra and frame records from the analysis to the synthesis (2), pitch spectra / resynthesised
+    // frames from the network half of the synthesis to its resynthesis half (2).
     xh_floats = (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame);
     ws_cells = cells;
     if ((err = hipMalloc(&d_xh, sizeof(float) * kXhBuffers * xh_floats)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_X, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
-    if ((err = hipMalloc(&d_P, sizeof(float2) * cells * kRnnFreq)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_P, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * 2 * cells)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_ds, sizeof(float) * cells * (kPitchBuf / 2))) != hipSuccess) return err;
     ws_frames = frames;

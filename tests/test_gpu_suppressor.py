@@ -149,9 +149,9 @@ def test_split_chain_is_bit_identical_to_one_launch(mi):
 
 
 def test_ramped_window_schedule_matches_restatement(mi, oracle):
-    """A call long enough for the ramped window schedule (windows of 4, 8, 16, 30 ..., 16, 8, 4 frames,
+    """A call long enough for the ramped window schedule (windows of 4, 8, 16, 20 ..., 16, 8, 4 frames,
     af_api.cpp) must give what frame-by-frame processing gives: the windows are an execution detail."""
-    audio = S.batch_signal(18, 260)  # 2.6 s: 4+8+16 | 30 x 6, 24 | 16+8+4
+    audio = S.batch_signal(18, 260)  # 2.6 s: 4+8+16 | 20 x 10, 4 | 16+8+4
     want = np.stack([oracle.suppressor_process(audio[s], 1.0, 0x5EED) for s in range(audio.shape[0])])
     got = mi.suppress(audio, 1.0, 0x5EED)
     _check(got, want)
