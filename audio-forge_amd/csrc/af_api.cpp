@@ -335,12 +335,12 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
                        af::quad_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   int kernel = e->kernel;
   if (kernel == AF_KERNEL_AUTO) {
-    // Kernel 2 (64 streams per workgroup) spends the fewest issue slots per stream-sample; kernel 3 (16 streams per
-    // workgroup) spends ~1.3x more but reaches four times as many CUs.  So: kernel 3 when the batch alone cannot
-    // fill the chip and nothing else wants the idle CUs; kernel 2 when the suppressor's kernels run alongside.
-    const bool chip_has_room = !e->supp.enabled && (e->n_streams + 63) / 64 < 256;
-    kernel = (quad_ok && (chip_has_room || !ring_fits)) ? AF_KERNEL_QUAD
-             : (ring_fits ? AF_KERNEL_PHASED : AF_KERNEL_LANE_PER_STREAM);
+    // Kernel 2 (the token ring, 64 streams per workgroup) wherever its LDS fits: a launch lasts as long as ONE
+    // workgroup needs for its streams' samples, whatever the batch, and since its waves carry priorities (in a serial
+    // unit, and growing with the age of their chunk) that is shorter than kernel 3's (16 streams per workgroup, which
+    // the same priorities slow down): 206-212 vs 217-225 ms for 4096 streams x 10 s of the dynamics chain, 209 vs 212 ms
+    // for 256 streams.  Kernel 3 serves configurations whose limiter ring does not fit kernel 2's LDS layout.
+    kernel = ring_fits ? AF_KERNEL_PHASED : (quad_ok ? AF_KERNEL_QUAD : AF_KERNEL_LANE_PER_STREAM);
   }
   if (kernel == AF_KERNEL_QUAD && !quad_ok)
     return fail(AF_ERR_UNSUPPORTED, "the quad kernel does not build auto-makeup or the EQ-before-de-esser order; use AF_KERNEL_PHASED");

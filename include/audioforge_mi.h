@@ -208,9 +208,9 @@ int64_t af_engine_last_block_count(const af_engine *e);
 int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capacity);
 /* total samples per stream processed since create/reset */
 int64_t af_engine_samples_processed(const af_engine *e);
-/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: AF_KERNEL_QUAD (16 streams per workgroup)
- * when the batch alone cannot fill the chip, AF_KERNEL_PHASED (64 streams per workgroup) otherwise and whenever
- * auto-makeup or the EQ-before-de-esser order need its pre-pass mode */
+/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: AF_KERNEL_PHASED (the token ring, 64 streams per
+ * workgroup) wherever its LDS layout fits, AF_KERNEL_QUAD (16 streams per workgroup) for longer limiter lookaheads,
+ * AF_KERNEL_LANE_PER_STREAM otherwise */
 int af_engine_set_kernel(af_engine *e, int32_t kernel);
 /* The token-ring chain can run each suppressor window as two launches on different CUs (head: front end, EQ,
  * compressor detector; tail: gain smoothing, limiter, true peak).  Results are bit-identical to the one-launch form;
