@@ -105,10 +105,12 @@ __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
 #endif
   __hip_atomic_store(&turn_base[tok], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   // Between serial units a wave keeps a priority that grows with the age of its chunk (a later stage means an older
-  // chunk, and every unit is first-come-first-served, so the oldest chunk gates all others): chain time 237 -> 219 ms
-  // per bench step on top of the in-unit priority.
-  if (tok == kTokCompA || tok == kTokCompC) __builtin_amdgcn_s_setprio(1);
-  else if (tok == kTokCompE || tok == kTokLim || tok == kTokTp) __builtin_amdgcn_s_setprio(2);
+  // chunk, and every unit is first-come-first-served, so the oldest chunk gates all others): chain time 237 -> 216 ms
+  // per bench step on top of the in-unit priority (four levels; with three 219 ms; making the in-unit priority follow the
+  // stage as well: 245 ms).
+  if (tok == kTokEq0 + 1 || tok == kTokCompA) __builtin_amdgcn_s_setprio(1);
+  else if (tok == kTokCompC || tok == kTokCompE) __builtin_amdgcn_s_setprio(2);
+  else if (tok == kTokLim || tok == kTokTp) __builtin_amdgcn_s_setprio(3);
   else __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 }
