@@ -521,6 +521,7 @@ struct alignas(16) PitchSearchLds {
   float xc[304];
   float numa[304], da[304];
   float syy[304];
+  float d4[kPitchBuf / 4];  // every second sample of ds: the 4x-decimated buffer, contiguous (stride-2 reads of ds are 2-way bank conflicts)
 };
 extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(SuppArgs a, SuppTables tb) {
   __shared__ PitchSearchLds L;
@@ -598,18 +599,21 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
     {
       // coarse: 4x decimated, 147 lags x 240 products (lane per lag, left-to-right order)
       constexpr int len = kRnnWindow >> 2, mp = (kPitchMax - 3 * kPitchMin) >> 2;
+      for (int i = lane; i < kPitchBuf / 4; i += 64) L.d4[i] = L.ds[2 * i];
+      __syncthreads();
       {
         // the three lag rounds (lane, lane + 64, lane + 128) share every x-value: one loop, three running sums
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        const float *y = L.ds + 2 * lane;
-        const bool third = lane + 128 < mp;  // lags >= mp are never stored; keep their reads inside ds
-        const float *y2 = third ? y + 256 : y;
+        const float *x4 = L.d4 + (kPitchMax >> 2);  // x_lp[2 j]
+        const float *y = L.d4 + lane;                // y[2 (j + lag)]
+        const bool third = lane + 128 < mp;  // lags >= mp are never stored; keep their reads inside d4
+        const float *y2 = third ? y + 128 : y;
 #pragma unroll 8
         for (int j = 0; j < len; ++j) {
-          const float xs = x_lp[2 * j];
-          s0 += xs * y[2 * j];
-          s1 += xs * y[2 * j + 128];
-          s2 += xs * y2[2 * j];
+          const float xs = x4[j];
+          s0 += xs * y[j];
+          s1 += xs * y[j + 64];
+          s2 += xs * y2[j];
         }
 #pragma unroll
         for (int round = 0; round < 3; ++round) {
@@ -618,12 +622,19 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
             const float sum = round == 0 ? s0 : (round == 1 ? s1 : s2);
             const float x16 = sum * 1e-12f;
             L.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
-            const float ya = L.ds[2 * (lag + len)], yb = L.ds[2 * lag];
+            const float ya = L.d4[lag + len], yb = L.d4[lag];
             L.da[lag] = ya * ya - yb * yb;
           }
         }
       }
-      const float Syy0 = 1.0f + wave_dot64_sq_stride2(L.ds, len, lane);
+      float Syy0;
+      {
+        float acc = 0.0f;
+        for (int i = lane; i < len; i += 64) acc = acc + L.d4[i] * L.d4[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+        Syy0 = 1.0f + acc;
+      }
       __syncthreads();
       static_assert(mp == 147, "coarse lag count");
       best_pitch_scan<mp>(L.numa, L.da, L.syy, Syy0, lane, best0, best1);
