@@ -282,7 +282,7 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int la
 #pragma unroll
       for (int kb = 0; kb < 5; ++kb) {
         const int k1 = (10 * ka + 6 * kb) % 15;
-        a[k1 * 64 + lane] = cmul(y[kb], fl.tw960[k1]);
+        a[k1 * 72 + lane] = cmul(y[kb], fl.tw960[k1]);  // rows 72 apart: pass A's 8 x 8 reads of two rows hit disjoint banks
       }
     }
   }
@@ -293,10 +293,10 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int la
     const int id1 = lane + 64;
     const int k1a = lane >> 3, q = lane & 7, k1b = id1 >> 3;
 #pragma unroll
-    for (int pp = 0; pp < 8; ++pp) v0[pp] = a[k1a * 64 + 8 * pp + q];
+    for (int pp = 0; pp < 8; ++pp) v0[pp] = a[k1a * 72 + 8 * pp + q];
     if (id1 < 120) {
 #pragma unroll
-      for (int pp = 0; pp < 8; ++pp) v1[pp] = a[k1b * 64 + 8 * pp + q];
+      for (int pp = 0; pp < 8; ++pp) v1[pp] = a[k1b * 72 + 8 * pp + q];
     }
     __syncthreads();
     float2 V[8];
