@@ -602,24 +602,32 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
       for (int i = lane; i < kPitchBuf / 4; i += 64) L.d4[i] = L.ds[2 * i];
       __syncthreads();
       {
-        // the three lag rounds (lane, lane + 64, lane + 128) share every x-value: one loop, three running sums
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        const float *x4 = L.d4 + (kPitchMax >> 2);  // x_lp[2 j]
-        const float *y = L.d4 + lane;                // y[2 (j + lag)]
-        const bool third = lane + 128 < mp;  // lags >= mp are never stored; keep their reads inside d4
-        const float *y2 = third ? y + 128 : y;
-#pragma unroll 8
-        for (int j = 0; j < len; ++j) {
-          const float xs = x4[j];
-          s0 += xs * y[j];
-          s1 += xs * y[j + 64];
-          s2 += xs * y2[j];
+        // xcorr[lag] = sum_j x[j] y[j + lag] on the matrix cores.  Write lag = 16 c + i and j = 4 s + k - 16 c: then
+        //   D[i][c] += A[i][k] B[k][c],  A[i][k] = y[4 s + k + i],  B[k][c] = x[4 s + k - 16 c] (0 outside the frame),
+        // summed over the steps s = 0..95, visits every j in ascending order for each (i, c), one fused multiply-add
+        // per term (v_mfma_f32_16x16x4_f32 accumulates its four k in order): exactly inner_prod_fma of the CPU
+        // restatement.  A zero B entry leaves the accumulator unchanged.  ~4 vector instructions per step instead of the
+        // 16 (and 10 LDS reads) of the lane-per-lag loop this replaces.
+        typedef float v4f_ps __attribute__((ext_vector_type(4)));
+        v4f_ps acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int col = lane & 15, kq = lane >> 4;
+        const float *ap = L.d4 + kq + col;                    // y[4 s + k + i]
+        const float *x4 = L.d4 + (kPitchMax >> 2);            // x[j] = x_lp[2 j]
+        int xi = kq - 16 * col;                               // 4 s + k - 16 c at s = 0
+#pragma unroll 4
+        for (int s = 0; s < 96; ++s) {
+          const float av = ap[4 * s];
+          const bool in = (unsigned)xi < (unsigned)len;
+          const float bv = in ? x4[in ? xi : 0] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+          xi += 4;
         }
+        // acc[r]: row i = (lane >> 4) * 4 + r, column c = lane & 15
 #pragma unroll
-        for (int round = 0; round < 3; ++round) {
-          const int lag = lane + 64 * round;
+        for (int r = 0; r < 4; ++r) {
+          const int lag = 16 * col + kq * 4 + r;
           if (lag < mp) {
-            const float sum = round == 0 ? s0 : (round == 1 ? s1 : s2);
+            const float sum = acc[r];
             const float x16 = sum * 1e-12f;
             L.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
             const float ya = L.d4[lag + len], yb = L.d4[lag];

@@ -179,13 +179,8 @@ static void dct(float *out, const float *in) {
  *                   combined by the xor butterfly p[l] += p[l^32], ^16, ^8, ^4, ^2, ^1.
  *   scan64(e, n):   prefix sums with each lane owning ceil(n/64) consecutive terms: sequential prefix inside
  *                   a lane, Hillis-Steele inclusive scan of the 64 lane totals, one add of the offset.
- * The short lag-parallel correlations (coarse pitch search) keep the plain left-to-right order. */
-static float inner_prod(const float *x, const float *y, int n) {
-  float s = 0;
-  for (int i = 0; i < n; ++i) s += x[i] * y[i];
-  return s;
-}
-
+ * The short lag-parallel correlations (coarse pitch search) keep the plain left-to-right order, each term one fused
+ * multiply-add (inner_prod_fma): that is what a matrix-core instruction evaluates, and the GPU runs them there. */
 static float dot64(const float *x, const float *y, int n) {
   float p[64];
   for (int l = 0; l < 64; ++l) {
@@ -228,8 +223,14 @@ static void scan64(const float *e, float *out, int n) {
     }
 }
 
+static float inner_prod_fma(const float *x, const float *y, int n) {
+  float s = 0;
+  for (int i = 0; i < n; ++i) s = fmaf(x[i], y[i], s);
+  return s;
+}
+
 static void pitch_xcorr(const float *x, const float *y, float *xcorr, int len, int max_pitch) {
-  for (int i = 0; i < max_pitch; ++i) xcorr[i] = inner_prod(x, y + i, len);
+  for (int i = 0; i < max_pitch; ++i) xcorr[i] = inner_prod_fma(x, y + i, len);
 }
 
 static void celt_lpc4(float *lpc, const float *ac) {
