@@ -130,6 +130,15 @@ struct af_engine {
   hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
   std::vector<hipEvent_t> sync_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
+  // rnnoise.rs:114-164: the samples of a call that do not fill a 480-sample frame wait here for the next call
+  float *d_pending = nullptr;   // [streams][480]
+  int pending = 0;              // samples per stream waiting in d_pending (all streams advance in lock step)
+  float *d_asm = nullptr;       // [streams][asm_stride]: pending samples + this call's, when the two have to be joined
+  int64_t asm_capacity = 0;     // floats
+  int64_t last_output_samples = 0;  // samples per stream the last process call produced
+  int32_t *d_trace = nullptr;   // [frames][streams][2]: (silence, pitch index) of every frame of the last call
+  int64_t trace_capacity = 0, trace_frames = 0;
+  bool trace = false;
   int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
@@ -275,6 +284,7 @@ int ensure_started(af_engine *e) {
     e->params_dirty = true;
     e->started = true;
     e->samples_processed = 0;
+    e->pending = 0;
   }
   return AF_OK;
 }
@@ -604,7 +614,7 @@ int af_engine_create(double sample_rate, int32_t n_streams, int32_t device, af_e
 
 void af_engine_destroy(af_engine *e) {
   if (!e) return;
-  if (e->d_params || e->d_st64 || e->d_stats || e->d_io) {
+  if (e->d_params || e->d_st64 || e->d_stats || e->d_io || e->d_pending || e->d_asm || e->d_trace) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(e->d_params);
@@ -618,6 +628,9 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_vad);
     (void)hipFree(e->d_status);
     (void)hipFree(e->d_io);
+    (void)hipFree(e->d_pending);
+    (void)hipFree(e->d_asm);
+    (void)hipFree(e->d_trace);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
@@ -652,6 +665,9 @@ int af_engine_reset(af_engine *e) {
   e->params_dirty = true;
   e->samples_processed = 0;
   e->last_blocks = 0;
+  e->pending = 0;
+  e->last_output_samples = 0;
+  e->trace_frames = 0;
   return AF_OK;
 }
 
@@ -849,6 +865,53 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (int rc = ensure_started(e)) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
   e->last_stream = stream;
+  // ---- RNNoise frame buffering (rnnoise.rs:114-164: push_samples -> process_frames -> pop).  The suppressor eats whole
+  // 480-sample frames; what a call leaves over waits in the engine for the next call, and a call returns the whole frames
+  // that are complete by then: floor((pending + n) / 480) * 480 samples per stream, which may be 0 or exceed n.
+  const float *src = in;
+  int64_t src_stride = stream_stride;
+  const int64_t n_in = n_samples;
+  if (e->supp.enabled) {
+    if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
+    const int64_t B = e->n_streams;
+    const int64_t total = e->pending + n_in;
+    const int64_t n_run = (total / af::kRnnFrame) * af::kRnnFrame;
+    const int64_t rem = total - n_run;
+    if (n_run > stream_stride)
+      return fail(AF_ERR_INVALID_ARGUMENT, "this call completes %lld samples per stream (%d were pending): stream_stride %lld is too small",
+                  (long long)n_run, e->pending, (long long)stream_stride);
+    if (e->pending > 0 || rem > 0) {
+      if (!e->d_pending) AF_HIP(hipMalloc(&e->d_pending, sizeof(float) * af::kRnnFrame * B));
+      const size_t f4 = sizeof(float);
+      if (n_run > 0) {
+        if (B * n_run > e->asm_capacity) {
+          AF_HIP(hipDeviceSynchronize());
+          if (e->d_asm) AF_HIP(hipFree(e->d_asm));
+          e->d_asm = nullptr;
+          AF_HIP(hipMalloc(&e->d_asm, f4 * B * n_run));
+          e->asm_capacity = B * n_run;
+        }
+        // [pending | head of this call] -> whole frames; the tail of this call waits (copied before anything writes `out`,
+        // which may alias `in`)
+        if (e->pending > 0)
+          AF_HIP(hipMemcpy2DAsync(e->d_asm, f4 * n_run, e->d_pending, f4 * af::kRnnFrame, f4 * e->pending, B, hipMemcpyDeviceToDevice, stream));
+        AF_HIP(hipMemcpy2DAsync(e->d_asm + e->pending, f4 * n_run, in, f4 * stream_stride, f4 * (n_run - e->pending), B,
+                                hipMemcpyDeviceToDevice, stream));
+        if (rem > 0)
+          AF_HIP(hipMemcpy2DAsync(e->d_pending, f4 * af::kRnnFrame, in + (n_in - rem), f4 * stream_stride, f4 * rem, B,
+                                  hipMemcpyDeviceToDevice, stream));
+        src = e->d_asm;
+        src_stride = n_run;
+      } else if (n_in > 0) {
+        AF_HIP(hipMemcpy2DAsync(e->d_pending + e->pending, f4 * af::kRnnFrame, in, f4 * stream_stride, f4 * n_in, B,
+                                hipMemcpyDeviceToDevice, stream));
+      }
+      e->pending = (int)rem;
+    }
+    n_samples = n_run;
+  }
+  e->last_output_samples = n_samples;
+  e->trace_frames = 0;
   const int cb = e->host_params.control_block;
   const int64_t blocks = (n_samples + cb - 1) / cb;
   e->last_blocks = blocks;
@@ -902,10 +965,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   //   caller stream : window w's pitch-aligned spectra, network, resynthesis, overlap-add
   //   chain stream  : window w-1's chain launch (64 streams per workgroup, a quarter of the CUs at batch 4096)
   // ordered by events; buffers that cross a stage boundary rotate (af_suppressor_host.hpp).
-  if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
-  if (n_samples % af::kRnnFrame != 0)
-    return fail(AF_ERR_INVALID_ARGUMENT, "with the suppressor on, n_samples must be a multiple of %d (one RNNoise frame)",
-                af::kRnnFrame);
   if (e->supp.weights_dirty) AF_HIP(e->supp.upload());
   af::ChainParams run = e->host_params;
   bool run_modified = false;
@@ -923,11 +982,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   while ((unit * af::kRnnFrame) % cb != 0) ++unit;
   int window_frames = e->supp_window_frames;
   if (const char *env = std::getenv("AF_SUPP_WINDOW_FRAMES")) window_frames = std::max(1, std::atoi(env));  // tuning runs
+  // Only the last control block of a call can be short, so the call is scheduled as aligned windows over its whole control
+  // blocks plus one short final window for a ragged end: block boundaries do not move and the pipeline keeps its overlap.
+  const int64_t aligned = (frames / unit) * unit, ragged = frames - aligned;
   int64_t window = std::max<int64_t>(unit, (window_frames / unit) * unit);
-  const bool windows_align = frames % unit == 0 || frames <= window;
-  if (!windows_align) window = frames;  // ragged tail: one window (workspace permitting)
-  window = std::min<int64_t>(window, frames);
-  AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)window));
+  window = std::min<int64_t>(window, std::max<int64_t>(aligned, unit));
   // Window schedule.  The first chain launch cannot start before one window has been through the pre-pass, the analysis
   // and the synthesis, and the last chain launch runs after everything else is done: with uniform windows that is ~2.5
   // window times of a 20-window call during which most of the chip idles.  So the call opens with short windows that
@@ -942,18 +1001,34 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     for (int64_t n = ((4 + unit - 1) / unit) * unit; n < window; n *= 2) up.push_back(n);
     int64_t up_total = 0;
     for (int64_t n : up) up_total += n;
-    if (ramp && windows_align && !up.empty() && frames >= 2 * up_total + 2 * window) {
+    if (ramp && !up.empty() && aligned >= 2 * up_total + 2 * window) {
       int64_t f = 0;
       for (int64_t n : up) { win_f0.push_back(f); win_nf.push_back(n); f += n; }
-      const int64_t body_end = frames - up_total;
+      const int64_t body_end = aligned - up_total;
       while (f < body_end) {
         const int64_t n = std::min<int64_t>(window, body_end - f);
         win_f0.push_back(f); win_nf.push_back(n); f += n;
       }
       for (auto it = up.rbegin(); it != up.rend(); ++it) { win_f0.push_back(f); win_nf.push_back(*it); f += *it; }
     } else {
-      for (int64_t f = 0; f < frames; f += window) { win_f0.push_back(f); win_nf.push_back(std::min<int64_t>(window, frames - f)); }
+      for (int64_t f = 0; f < aligned; f += window) { win_f0.push_back(f); win_nf.push_back(std::min<int64_t>(window, aligned - f)); }
     }
+    if (ragged > 0) { win_f0.push_back(aligned); win_nf.push_back(ragged); }
+  }
+  {
+    int64_t longest = 1;
+    for (int64_t n : win_nf) longest = std::max(longest, n);
+    AF_HIP(e->supp.ensure_workspace(e->n_streams, (int)longest));
+  }
+  if (e->trace) {
+    if (frames * e->n_streams > e->trace_capacity) {
+      AF_HIP(hipDeviceSynchronize());
+      if (e->d_trace) AF_HIP(hipFree(e->d_trace));
+      e->d_trace = nullptr;
+      AF_HIP(hipMalloc(&e->d_trace, sizeof(int32_t) * 2 * frames * e->n_streams));
+      e->trace_capacity = frames * e->n_streams;
+    }
+    e->trace_frames = frames;
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
     e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = e->fin_stream = stream;
@@ -1051,7 +1126,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
     af::SuppArgs sa{};
-    sa.in = in;
+    sa.in = src;
+    sa.in_stride = src_stride;
     sa.out = out;
     sa.xh = e->supp.d_xh + (size_t)(index % kXh) * e->supp.xh_floats;
     sa.X = e->supp.d_X + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
@@ -1124,6 +1200,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(syn, ana_done[w], 0));
     if (fin && fin != syn && w >= 2) AF_HIP(hipStreamWaitEvent(syn, syn_done[w - 2], 0));  // its pitch-spectrum buffer is free
     AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w], fin));
+    if (e->trace) {  // the window's (silence, pitch index) decisions, before its record buffer is handed back to the analysis
+      const af::SuppArgs sa = window_args(f0, nf, w);
+      AF_HIP(hipMemcpy2DAsync(e->d_trace + 2 * f0 * e->n_streams, 2 * sizeof(int32_t),
+                              reinterpret_cast<const char *>(sa.rec) + offsetof(af::SuppFrameRec, silence), sizeof(af::SuppFrameRec),
+                              2 * sizeof(int32_t), (size_t)(nf * e->n_streams), hipMemcpyDeviceToDevice, (fin && fin != syn) ? fin : syn));
+    }
     AF_HIP(hipEventRecord(syn_done[w], (fin && fin != syn) ? fin : syn));
     e->last_launches += 7;
     if (w + 2 < n_windows)
@@ -1188,23 +1270,92 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   return AF_OK;
 }
 
-int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_samples, int32_t layout) {
+// host buffers in, host buffers out: `in` is [streams][n_in] (stream-major) or [n_in][streams] (time-major), `out` gets
+// *n_out samples per stream at out_stride (stream-major) -- n_out differs from n_in only with the suppressor on
+static int process_host_impl(af_engine *e, const float *in, int64_t n_in, float *out, int64_t out_stride, int32_t layout,
+                             int64_t *n_out) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  if (n_samples < 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
-  if (n_samples > 0 && (!in || !out)) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
+  if (n_in < 0) return fail(AF_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+  if (n_in > 0 && (!in || !out)) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
   if (int rc = ensure_started(e)) return rc;
-  const int64_t total = n_samples * e->n_streams;
+  const int64_t B = e->n_streams;
+  const bool stream_major = layout == AF_LAYOUT_STREAM_MAJOR;
+  int64_t produced = n_in;
+  if (e->supp.enabled) produced = ((e->pending + n_in) / af::kRnnFrame) * af::kRnnFrame;
+  if (produced > 0 && !out) return fail(AF_ERR_INVALID_ARGUMENT, "audio pointers are null");
+  if (stream_major && out_stride < produced)
+    return fail(AF_ERR_INVALID_ARGUMENT, "this call completes %lld samples per stream (%d were pending) but `out` holds %lld: "
+                "use af_engine_stream_host with a larger out_stride", (long long)produced, e->pending, (long long)out_stride);
+  const int64_t io_stride = stream_major ? std::max<int64_t>(std::max(n_in, produced), 1) : B;
+  const int64_t total = stream_major ? io_stride * B : n_in * B;
   if (total > e->io_capacity) {
     if (e->d_io) AF_HIP(hipFree(e->d_io));
+    e->d_io = nullptr;
     AF_HIP(hipMalloc(&e->d_io, sizeof(float) * total));
     e->io_capacity = total;
   }
-  if (total > 0) AF_HIP(hipMemcpy(e->d_io, in, sizeof(float) * total, hipMemcpyHostToDevice));
-  const int64_t stride = layout == AF_LAYOUT_STREAM_MAJOR ? n_samples : e->n_streams;
-  if (int rc = af_engine_process_device(e, e->d_io, e->d_io, n_samples, stride, layout, nullptr)) return rc;
+  if (n_in > 0) {
+    if (stream_major)
+      AF_HIP(hipMemcpy2D(e->d_io, sizeof(float) * io_stride, in, sizeof(float) * n_in, sizeof(float) * n_in, B, hipMemcpyHostToDevice));
+    else
+      AF_HIP(hipMemcpy(e->d_io, in, sizeof(float) * total, hipMemcpyHostToDevice));
+  }
+  if (int rc = af_engine_process_device(e, e->d_io, e->d_io, n_in, io_stride, layout, nullptr)) return rc;
   AF_HIP(hipStreamSynchronize(nullptr));
-  if (total > 0) AF_HIP(hipMemcpy(out, e->d_io, sizeof(float) * total, hipMemcpyDeviceToHost));
+  if (produced > 0) {
+    if (stream_major)
+      AF_HIP(hipMemcpy2D(out, sizeof(float) * out_stride, e->d_io, sizeof(float) * io_stride, sizeof(float) * produced, B, hipMemcpyDeviceToHost));
+    else
+      AF_HIP(hipMemcpy(out, e->d_io, sizeof(float) * total, hipMemcpyDeviceToHost));
+  }
+  if (n_out) *n_out = produced;
   return check_device_status(e);
+}
+
+int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_samples, int32_t layout) {
+  if (layout != AF_LAYOUT_STREAM_MAJOR && layout != AF_LAYOUT_TIME_MAJOR)
+    return fail(AF_ERR_INVALID_ARGUMENT, "unknown layout %d", layout);
+  return process_host_impl(e, in, n_samples, out, layout == AF_LAYOUT_STREAM_MAJOR ? n_samples : (e ? e->n_streams : 0), layout, nullptr);
+}
+
+int af_engine_stream_host(af_engine *e, const float *in, int64_t n_in, float *out, int64_t out_stride, int64_t *n_out) {
+  if (n_out) *n_out = 0;
+  return process_host_impl(e, in, n_in, out, out_stride, AF_LAYOUT_STREAM_MAJOR, n_out);
+}
+
+int64_t af_engine_pending_input(const af_engine *e) { return e ? e->pending : 0; }
+int64_t af_engine_last_output_samples(const af_engine *e) { return e ? e->last_output_samples : 0; }
+
+// test tap: RNNoiseProcessor::scale_sample_for_model (rnnoise.rs:89-111) as the pre-pass kernel evaluates it
+int af_suppressor_debug_scale_for_model(const float *in, float *out, int64_t n, int32_t device) {
+  if ((!in || !out) && n > 0) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  if (n <= 0) return AF_OK;
+  AF_HIP(hipSetDevice(device));
+  float *d = nullptr;
+  AF_HIP(hipMalloc(&d, sizeof(float) * n));
+  hipError_t err = hipMemcpy(d, in, sizeof(float) * n, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = af::launch_scale_probe(d, d, n, nullptr);
+  if (err == hipSuccess) err = hipMemcpy(out, d, sizeof(float) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(AF_ERR_BACKEND, "scale probe failed: %s", hipGetErrorString(err));
+  return AF_OK;
+}
+
+int af_suppressor_set_trace_enabled(af_engine *e, int32_t on) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  e->trace = on != 0;
+  return AF_OK;
+}
+int64_t af_suppressor_trace_frames(const af_engine *e) { return e ? e->trace_frames : 0; }
+int af_suppressor_read_trace(af_engine *e, int32_t *out, int64_t capacity_frames) {
+  if (!e || !out) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  if (capacity_frames < e->trace_frames)
+    return fail(AF_ERR_INVALID_ARGUMENT, "capacity %lld < %lld frames", (long long)capacity_frames, (long long)e->trace_frames);
+  if (e->trace_frames == 0) return AF_OK;
+  AF_HIP(hipSetDevice(e->device));
+  AF_HIP(hipStreamSynchronize(e->last_stream));
+  AF_HIP(hipMemcpy(out, e->d_trace, sizeof(int32_t) * 2 * e->trace_frames * e->n_streams, hipMemcpyDeviceToHost));
+  return AF_OK;
 }
 
 int af_engine_synchronize(af_engine *e) {
@@ -1691,5 +1842,195 @@ int af_gate_process_host(const float *in, float *out, int64_t n_samples, int32_t
   if (err != hipSuccess) return fail(AF_ERR_BACKEND, "gate failed: %s", hipGetErrorString(err));
   return AF_OK;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// NoiseSuppressor (rust-core/src/dsp/noise_suppressor.rs:89-194) for a batch of streams: the trait's ring surface over an
+// engine that runs the suppressor alone.  All streams advance in lock step, so the two fixed rings of
+// RNNoiseProcessor (rnnoise.rs:11,27-28; audio/rt.rs:146-248) are one pair of [stream][capacity] host buffers with shared
+// counters; whole frames go through the GPU in one call per process_frames().
+struct af_noise_suppressor {
+  af_engine *engine = nullptr;
+  int32_t model = AF_NOISE_MODEL_RNNOISE;
+  int32_t n_streams = 0;
+  bool enabled = true;  // rnnoise.rs:58
+  float strength = 1.0f;
+  std::vector<float> in_ring, out_ring;  // [stream][kCapacity], linear (compacted on pop)
+  int64_t in_len = 0, out_len = 0;
+  std::vector<float> scratch_in, scratch_out;
+  static constexpr int64_t kCapacity = 8192 + af::kRnnFrame;  // RNNOISE_BUFFER_CAPACITY, rnnoise.rs:11
+};
+
+extern "C" {
+
+int af_noise_model_from_id(const char *id, int32_t *model) {  // NoiseModel::from_id, noise_suppressor.rs:58-67
+  if (!id || !model) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  std::string lower(id);
+  for (char &c : lower) c = (char)std::tolower((unsigned char)c);
+  if (lower == "rnnoise") { *model = AF_NOISE_MODEL_RNNOISE; return AF_OK; }
+  if (lower == "deepfilter-ll" || lower == "deepfilterll") { *model = AF_NOISE_MODEL_DEEPFILTER_LL; return AF_OK; }
+  if (lower == "deepfilter" || lower == "deepfilternet") { *model = AF_NOISE_MODEL_DEEPFILTER; return AF_OK; }
+  return fail(AF_ERR_INVALID_ARGUMENT, "unknown noise model id '%s'", id);
+}
+const char *af_noise_model_id(int32_t model) {  // noise_suppressor.rs:47-55
+  switch (model) {
+    case AF_NOISE_MODEL_RNNOISE: return "rnnoise";
+    case AF_NOISE_MODEL_DEEPFILTER_LL: return "deepfilter-ll";
+    case AF_NOISE_MODEL_DEEPFILTER: return "deepfilter";
+    default: return "";
+  }
+}
+const char *af_noise_model_display_name(int32_t model) {  // noise_suppressor.rs:36-44
+  switch (model) {
+    case AF_NOISE_MODEL_RNNOISE: return "RNNoise (Low Latency)";
+    case AF_NOISE_MODEL_DEEPFILTER_LL: return "DeepFilterNet LL (Fast)";
+    case AF_NOISE_MODEL_DEEPFILTER: return "DeepFilterNet (Best Quality)";
+    default: return "";
+  }
+}
+int32_t af_noise_model_available(int32_t *models, int32_t capacity) {  // NoiseModel::available, noise_suppressor.rs:70-84
+  // the DeepFilterNet variants exist in the reference only behind its `deepfilter` feature and a runtime-loaded df library +
+  // model archives; neither is built here, so the list is what a default build of the reference returns
+  if (models && capacity > 0) models[0] = AF_NOISE_MODEL_RNNOISE;
+  return 1;
+}
+
+int af_noise_suppressor_create(int32_t model, int32_t n_streams, int32_t device, af_noise_suppressor **out) {
+  if (!out) return fail(AF_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  if (model == AF_NOISE_MODEL_DEEPFILTER_LL || model == AF_NOISE_MODEL_DEEPFILTER)
+    return fail(AF_ERR_UNSUPPORTED, "the DeepFilterNet backend is not built: its model archives and runtime library are not "
+                                    "part of the reference checkout (deepfilter_ffi.rs:9-16); use 'rnnoise'");
+  if (model != AF_NOISE_MODEL_RNNOISE) return fail(AF_ERR_INVALID_ARGUMENT, "unknown noise model %d", model);
+  af_engine *e = nullptr;
+  if (int rc = af_engine_create(48000.0, n_streams, device, &e)) return rc;
+  e->proto.eq_enabled = e->proto.eq.enabled = false;
+  e->proto.compressor_enabled = e->proto.compressor.enabled = false;
+  e->proto.limiter_enabled = e->proto.limiter.enabled = false;
+  e->proto.input_scrub = false;  // scale_sample_for_model zeroes non-finite model input itself (rnnoise.rs:90-93)
+  e->proto.control_block = af::kRnnFrame;
+  e->supp.enabled = true;
+  af_noise_suppressor *s = new af_noise_suppressor();
+  s->engine = e;
+  s->model = model;
+  s->n_streams = n_streams;
+  s->in_ring.assign((size_t)n_streams * af_noise_suppressor::kCapacity, 0.0f);
+  s->out_ring.assign((size_t)n_streams * af_noise_suppressor::kCapacity, 0.0f);
+  *out = s;
+  return AF_OK;
+}
+void af_noise_suppressor_destroy(af_noise_suppressor *s) {
+  if (!s) return;
+  af_engine_destroy(s->engine);
+  delete s;
+}
+af_engine *af_noise_suppressor_engine(af_noise_suppressor *s) { return s ? s->engine : nullptr; }
+
+// push_samples: `samples` is [stream][stride]; returns how many samples per stream the fixed input ring accepted
+int64_t af_noise_suppressor_push_samples(af_noise_suppressor *s, const float *samples, int64_t n, int64_t stride) {
+  if (!s || (!samples && n > 0) || n < 0 || stride < n) return fail(AF_ERR_INVALID_ARGUMENT, "bad push_samples arguments");
+  const int64_t cap = af_noise_suppressor::kCapacity;
+  const int64_t written = std::min<int64_t>(n, cap - s->in_len);  // FixedAudioRing::push_slice, rt.rs:189-197
+  for (int32_t k = 0; k < s->n_streams; ++k)
+    std::memcpy(&s->in_ring[(size_t)k * cap + s->in_len], samples + (size_t)k * stride, sizeof(float) * written);
+  s->in_len += written;
+  return written;
+}
+
+static void ring_consume(std::vector<float> &ring, int64_t &len, int64_t count, int32_t n_streams) {
+  const int64_t cap = af_noise_suppressor::kCapacity;
+  if (count <= 0) return;
+  for (int32_t k = 0; k < n_streams; ++k)
+    std::memmove(&ring[(size_t)k * cap], &ring[(size_t)k * cap + count], sizeof(float) * (len - count));
+  len -= count;
+}
+
+int af_noise_suppressor_process_frames(af_noise_suppressor *s) {  // rnnoise.rs:122-164
+  if (!s) return fail(AF_ERR_INVALID_ARGUMENT, "suppressor is null");
+  const int64_t cap = af_noise_suppressor::kCapacity;
+  if (!s->enabled) {  // bypass: input_buffer.move_into(&mut output_buffer), rnnoise.rs:123-126
+    const int64_t moved = std::min<int64_t>(s->in_len, cap - s->out_len);
+    for (int32_t k = 0; k < s->n_streams; ++k)
+      std::memcpy(&s->out_ring[(size_t)k * cap + s->out_len], &s->in_ring[(size_t)k * cap], sizeof(float) * moved);
+    s->out_len += moved;
+    ring_consume(s->in_ring, s->in_len, moved, s->n_streams);
+    return AF_OK;
+  }
+  // while input.len() >= 480 && output.remaining() >= 480
+  const int64_t frames = std::min<int64_t>(s->in_len / af::kRnnFrame, (cap - s->out_len) / af::kRnnFrame);
+  if (frames <= 0) return AF_OK;
+  const int64_t n = frames * af::kRnnFrame;
+  s->scratch_in.resize((size_t)s->n_streams * n);
+  s->scratch_out.resize((size_t)s->n_streams * n);
+  for (int32_t k = 0; k < s->n_streams; ++k)
+    std::memcpy(&s->scratch_in[(size_t)k * n], &s->in_ring[(size_t)k * cap], sizeof(float) * n);
+  if (int rc = af_engine_set_suppressor_strength(s->engine, s->strength)) return rc;
+  if (int rc = af_engine_process_host(s->engine, s->scratch_in.data(), s->scratch_out.data(), n, AF_LAYOUT_STREAM_MAJOR)) return rc;
+  for (int32_t k = 0; k < s->n_streams; ++k)
+    std::memcpy(&s->out_ring[(size_t)k * cap + s->out_len], &s->scratch_out[(size_t)k * n], sizeof(float) * n);
+  s->out_len += n;
+  ring_consume(s->in_ring, s->in_len, n, s->n_streams);
+  return AF_OK;
+}
+
+int64_t af_noise_suppressor_available_samples(const af_noise_suppressor *s) { return s ? s->out_len : 0; }
+int64_t af_noise_suppressor_pending_input(const af_noise_suppressor *s) { return s ? s->in_len : 0; }
+
+// pop_samples_into / read_samples (rnnoise.rs:185-188): up to `count` samples per stream into out[stream][stride]
+int64_t af_noise_suppressor_pop_samples_into(af_noise_suppressor *s, float *out, int64_t count, int64_t stride) {
+  if (!s || (!out && count > 0) || count < 0 || stride < count) return fail(AF_ERR_INVALID_ARGUMENT, "bad pop_samples_into arguments");
+  const int64_t cap = af_noise_suppressor::kCapacity;
+  const int64_t n = std::min<int64_t>(count, s->out_len);
+  for (int32_t k = 0; k < s->n_streams; ++k) std::memcpy(out + (size_t)k * stride, &s->out_ring[(size_t)k * cap], sizeof(float) * n);
+  ring_consume(s->out_ring, s->out_len, n, s->n_streams);
+  return n;
+}
+int64_t af_noise_suppressor_drain_pending_input(af_noise_suppressor *s, float *out, int64_t capacity, int64_t stride) {  // rnnoise.rs:240-244
+  if (!s || (!out && capacity > 0) || capacity < 0 || stride < capacity) return fail(AF_ERR_INVALID_ARGUMENT, "bad drain_pending_input arguments");
+  const int64_t cap = af_noise_suppressor::kCapacity;
+  const int64_t n = std::min<int64_t>(capacity, s->in_len);
+  for (int32_t k = 0; k < s->n_streams; ++k) std::memcpy(out + (size_t)k * stride, &s->in_ring[(size_t)k * cap], sizeof(float) * n);
+  ring_consume(s->in_ring, s->in_len, n, s->n_streams);
+  return n;
+}
+
+int af_noise_suppressor_set_strength(af_noise_suppressor *s, float value) {  // rnnoise.rs:67-72
+  if (!s) return fail(AF_ERR_INVALID_ARGUMENT, "suppressor is null");
+  s->strength = af::clampf(value, 0.0f, 1.0f);
+  return AF_OK;
+}
+float af_noise_suppressor_get_strength(const af_noise_suppressor *s) { return s ? s->strength : 0.0f; }
+int af_noise_suppressor_set_enabled(af_noise_suppressor *s, int32_t enabled) {  // rnnoise.rs:194-196: state is kept
+  if (!s) return fail(AF_ERR_INVALID_ARGUMENT, "suppressor is null");
+  s->enabled = enabled != 0;
+  return AF_OK;
+}
+int32_t af_noise_suppressor_is_enabled(const af_noise_suppressor *s) { return s && s->enabled ? 1 : 0; }
+int af_noise_suppressor_soft_reset(af_noise_suppressor *s) {  // flush_buffers, rnnoise.rs:216-232: model state survives
+  if (!s) return fail(AF_ERR_INVALID_ARGUMENT, "suppressor is null");
+  s->in_len = s->out_len = 0;
+  return AF_OK;
+}
+int af_noise_suppressor_reset(af_noise_suppressor *s) {  // rnnoise.rs:205-210: a new DenoiseState + empty rings
+  if (!s) return fail(AF_ERR_INVALID_ARGUMENT, "suppressor is null");
+  s->in_len = s->out_len = 0;
+  if (!s->engine->started) return AF_OK;
+  AF_HIP(hipSetDevice(s->engine->device));
+  AF_HIP(hipDeviceSynchronize());
+  // the wet/dry smoothing state belongs to the wrapper, not to DenoiseState: it survives (rnnoise.rs:205-210)
+  std::vector<float> smoothed((size_t)s->n_streams);
+  AF_HIP(hipMemcpy2D(smoothed.data(), sizeof(float), s->engine->supp.d_state + af::SuppState::kSmoothedStrength,
+                     sizeof(float) * af::SuppState::kCount, sizeof(float), s->n_streams, hipMemcpyDeviceToHost));
+  AF_HIP(s->engine->supp.reset_state(s->n_streams));
+  AF_HIP(hipMemcpy2D(s->engine->supp.d_state + af::SuppState::kSmoothedStrength, sizeof(float) * af::SuppState::kCount, smoothed.data(),
+                     sizeof(float), sizeof(float), s->n_streams, hipMemcpyHostToDevice));
+  return AF_OK;
+}
+int32_t af_noise_suppressor_model_type(const af_noise_suppressor *s) { return s ? s->model : -1; }
+int32_t af_noise_suppressor_latency_samples(const af_noise_suppressor *) { return af::kRnnFrame; }  // rnnoise.rs:313-315
+int32_t af_noise_suppressor_backend_available(const af_noise_suppressor *s) { return s ? 1 : 0; }   // rnnoise.rs:317-319
+int32_t af_noise_suppressor_backend_failed(const af_noise_suppressor *) { return 0; }               // rnnoise.rs:325-327
+const char *af_noise_suppressor_backend_error(const af_noise_suppressor *) { return nullptr; }      // rnnoise.rs:321-323
 
 }  // extern "C"

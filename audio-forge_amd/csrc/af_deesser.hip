@@ -133,9 +133,12 @@ __global__ __launch_bounds__(kLanes) void deesser_lane_kernel(DeEsserArgs a) {
     B[i].lp = Bq{p[15 * NS], p[16 * NS], p[17 * NS], p[18 * NS]};
     B[i].eq = Bq{p[19 * NS], p[20 * NS], p[21 * NS], p[22 * NS]};
   }
+  // The front-end memories belong to whoever runs the DC block: with the suppressor on that is its pre-pass, which
+  // may already be windows ahead of this launch -- touch them only when this pass filters (as the chain kernels do).
+  const bool owns_front_state = a.front_end && (flags & kFlagDcBlock);
   float dc_x1 = 0.0f, dc_y1 = 0.0f;
   double pre_z1 = 0.0, pre_z2 = 0.0;
-  if (a.front_end) {
+  if (owns_front_state) {
     dc_x1 = a.st32[(int64_t)kDcX1 * NS + sc];
     dc_y1 = a.st32[(int64_t)kDcY1 * NS + sc];
     pre_z1 = a.st64[(int64_t)kPreZ1 * NS + sc];
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(kLanes) void deesser_lane_kernel(DeEsserArgs a) {
 #pragma unroll
       for (int k = 0; k < 23; ++k) p[k * NS] = v[k];
     }
-    if (a.front_end) {
+    if (owns_front_state) {
       a.st32[(int64_t)kDcX1 * NS + s] = dc_x1;
       a.st32[(int64_t)kDcY1 * NS + s] = dc_y1;
       a.st64[(int64_t)kPreZ1 * NS + s] = pre_z1;

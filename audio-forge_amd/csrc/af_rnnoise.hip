@@ -62,6 +62,16 @@ __device__ __forceinline__ float scale_for_model(float sample) {
   return scaled < -kLimit ? -kLimit : (scaled > kLimit ? kLimit : scaled);
 }
 
+// test tap: the transfer function above, element-wise (the reference pins it in rnnoise.rs:335-352)
+__global__ void supp_scale_probe_kernel(const float *in, float *out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = scale_for_model(in[i]);
+}
+hipError_t launch_scale_probe(const float *in, float *out, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(supp_scale_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
 // The pass is a chain of short per-sample recurrences (DC block, 80 Hz high-pass in f64, the model's own
 // high-pass), so its duration is samples x recurrence latency whatever the lane count: one wave takes 64
 // streams (lane = stream), keeps a whole 64-sample tile of its stream in registers so that no LDS or HBM
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
 #pragma unroll
     for (int r = 0; r < kPreGroup; ++r) {
       const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
-      nxt[r] = a.in[(int64_t)sr * a.stream_stride + col];
+      nxt[r] = a.in[(int64_t)sr * a.in_stride + col];
     }
   };
   if (ntiles > 0) fetch(0);
@@ -1459,7 +1469,7 @@ extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a)
     for (int i = lane; i < kRnnFrame; i += 64) {
       float wet = (y[i] + prev[i]) / 32768.0f;
       if (!a.raw_protocol && smoothed < 1.0f) {
-        const float dry = (a.front_clamp || a.front_dc) ? a.out[base + i] : a.in[base + i];
+        const float dry = (a.front_clamp || a.front_dc) ? a.out[base + i] : a.in[(int64_t)s * a.in_stride + (a.frame0 + f) * kRnnFrame + i];
         wet = (smoothed * wet) + ((1.0f - smoothed) * dry);
       }
       a.out[base + i] = wet;

@@ -97,7 +97,8 @@ struct SuppArgs {
   float *ds;                  // [frame][stream][864] LPC-whitened, 2x-decimated pitch buffer (pitch part 1 -> part 2)
   SuppFrameRec *rec;          // [frame][stream]
   float *state;               // [stream][SuppState::kCount]
-  int64_t stream_stride;
+  int64_t stream_stride;      // of `out`
+  int64_t in_stride;          // of `in` (the engine's frame-assembly buffer when samples were pending, else = stream_stride)
   int32_t n_streams;
   int32_t n_frames;           // frames in this window
   int64_t frame0;             // first frame of the window inside `in`

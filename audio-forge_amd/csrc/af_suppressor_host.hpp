@@ -15,6 +15,7 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
                                        hipEvent_t after_network, hipStream_t finish_stream);
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
+hipError_t launch_scale_probe(const float *in, float *out, int64_t n, hipStream_t stream);
 
 // int8 network weights in the layout of the public RNNoise model (dense: [in][out]; GRU: [in][3*units],
 // gate order z | r | h).  The trained weights of nnnoiseless 0.5.2 are embedded in that crate and are not

@@ -45,6 +45,10 @@ CORE_AVAILABLE = _core_module is not None
 for _name in _OPERATORS:
     globals()[_name] = getattr(_core_module, _name, _missing_core) if _core_module is not None else _missing_core
 Engine = getattr(_core_module, "Engine", None) if _core_module is not None else None
+NoiseSuppressor = getattr(_core_module, "NoiseSuppressor", None) if _core_module is not None else None
+NoiseModel = getattr(_core_module, "NoiseModel", None) if _core_module is not None else None
+new_noise_suppression_engine = (getattr(_core_module, "new_noise_suppression_engine", _missing_core)
+                                if _core_module is not None else _missing_core)
 
-__all__ = ["CORE_AVAILABLE", "Engine", *_OPERATORS, "LAYOUT_STREAM_MAJOR", "LAYOUT_TIME_MAJOR", "KERNEL_AUTO",
+__all__ = ["CORE_AVAILABLE", "Engine", "NoiseSuppressor", "NoiseModel", "new_noise_suppression_engine", *_OPERATORS, "LAYOUT_STREAM_MAJOR", "LAYOUT_TIME_MAJOR", "KERNEL_AUTO",
            "KERNEL_LANE_PER_STREAM", "KERNEL_PHASED", "KERNEL_QUAD"]

@@ -122,6 +122,38 @@ SIGNATURES = {
     "af_engine_process_device": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "af_engine_process_host": (C.c_int, [_vp, _fp, _fp, _i64, _i32]),
     "af_engine_synchronize": (C.c_int, [_vp]),
+    "af_engine_stream_host": (C.c_int, [_vp, _fp, _i64, _fp, _i64, C.POINTER(_i64)]),
+    "af_engine_pending_input": (_i64, [_vp]),
+    "af_engine_last_output_samples": (_i64, [_vp]),
+    "af_suppressor_debug_scale_for_model": (C.c_int, [_fp, _fp, _i64, _i32]),
+    "af_suppressor_set_trace_enabled": (C.c_int, [_vp, _i32]),
+    "af_suppressor_trace_frames": (_i64, [_vp]),
+    "af_suppressor_read_trace": (C.c_int, [_vp, C.POINTER(_i32), _i64]),
+    # NoiseSuppressor (noise_suppressor.rs:18-194)
+    "af_noise_model_from_id": (C.c_int, [C.c_char_p, C.POINTER(_i32)]),
+    "af_noise_model_id": (C.c_char_p, [_i32]),
+    "af_noise_model_display_name": (C.c_char_p, [_i32]),
+    "af_noise_model_available": (_i32, [C.POINTER(_i32), _i32]),
+    "af_noise_suppressor_create": (C.c_int, [_i32, _i32, _i32, C.POINTER(_vp)]),
+    "af_noise_suppressor_destroy": (None, [_vp]),
+    "af_noise_suppressor_engine": (_vp, [_vp]),
+    "af_noise_suppressor_push_samples": (_i64, [_vp, _fp, _i64, _i64]),
+    "af_noise_suppressor_process_frames": (C.c_int, [_vp]),
+    "af_noise_suppressor_available_samples": (_i64, [_vp]),
+    "af_noise_suppressor_pending_input": (_i64, [_vp]),
+    "af_noise_suppressor_pop_samples_into": (_i64, [_vp, _fp, _i64, _i64]),
+    "af_noise_suppressor_drain_pending_input": (_i64, [_vp, _fp, _i64, _i64]),
+    "af_noise_suppressor_set_strength": (C.c_int, [_vp, _f]),
+    "af_noise_suppressor_get_strength": (_f, [_vp]),
+    "af_noise_suppressor_set_enabled": (C.c_int, [_vp, _i32]),
+    "af_noise_suppressor_is_enabled": (_i32, [_vp]),
+    "af_noise_suppressor_soft_reset": (C.c_int, [_vp]),
+    "af_noise_suppressor_reset": (C.c_int, [_vp]),
+    "af_noise_suppressor_model_type": (_i32, [_vp]),
+    "af_noise_suppressor_latency_samples": (_i32, [_vp]),
+    "af_noise_suppressor_backend_available": (_i32, [_vp]),
+    "af_noise_suppressor_backend_failed": (_i32, [_vp]),
+    "af_noise_suppressor_backend_error": (C.c_char_p, [_vp]),
     "af_engine_last_block_count": (_i64, [_vp]),
     "af_engine_read_block_stats": (C.c_int, [_vp, C.POINTER(BlockStats), _i64]),
     "af_engine_samples_processed": (_i64, [_vp]),
@@ -158,6 +190,7 @@ SIGNATURES = {
 VALUE_FUNCTIONS = {
     "af_version", "af_last_error", "af_device_count", "af_engine_n_streams", "af_limiter_ceiling_db",
     "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy", "af_engine_last_kernel",
+    "af_engine_pending_input", "af_engine_last_output_samples", "af_suppressor_trace_frames",
     "af_resampler_destroy", "af_resampler_output_delay", "af_resampler_expected_frames", "af_resampler_sinc_len",
 }
 

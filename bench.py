@@ -139,6 +139,54 @@ def cpu_baseline(seconds: float, full: bool, budget_s: float = 15.0) -> dict:
     }
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, LOCAL_RANK = RANK) with a
+    fresh rendezvous port and wait for them.  Runs BEFORE anything in this process touches a GPU (the parent never does:
+    counting devices does not initialise HIP), so no initialised process is ever re-executed.  Rank 0 prints the JSON line;
+    the return code is non-zero when any rank failed."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(rank), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this platform (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve()), *sys.argv[1:]], env=env))
+    worst = 0
+    for rank, proc in enumerate(procs):
+        rc = proc.wait()
+        if rc != 0:
+            print(f"bench.py: rank {rank} exited with code {rc}", file=sys.stderr)
+            worst = worst or (rc if rc > 0 else 1)
+    return worst
+
+
+class StubEngine:
+    """CPU rehearsal of the launch / sharding / reduction path (`--stub-engine`, tests/test_bench_launcher.py): no kernels,
+    block rows carry the input's own energy and peak.  A line produced with it is marked `"stub": true` and is not a
+    measurement."""
+
+    def __init__(self, streams: int, n: int, first_stream: int):
+        from mic_eq_mi import mic_eq_core as core
+
+        rng = np.random.default_rng(1234 + first_stream)
+        self.x = (rng.standard_normal((streams, n)) * 0.1).astype(np.float32)
+        blocks = n // 960
+        self.rows = np.zeros((blocks, streams), dtype=core.STATS_DTYPE)
+        xb = self.x[:, : blocks * 960].reshape(streams, blocks, 960).astype(np.float64)
+        self.rows["input_square_sum"] = (xb ** 2).sum(axis=2).T
+        self.rows["output_square_sum"] = self.rows["input_square_sum"]
+        self.rows["input_sample_peak"] = np.abs(xb).max(axis=2).T
+        self.rows["output_sample_peak"] = self.rows["input_sample_peak"]
+
+    def step(self) -> None:
+        float(np.square(self.x, dtype=np.float32).sum())
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,23 +200,46 @@ def main() -> None:
     ap.add_argument("--chain", choices=["full", "dynamics"], default="full",
                     help="full = DC/HP prefilter + RNNoise + EQ + compressor + limiter + true-peak (configs[2]); "
                          "dynamics = EQ + compressor + limiter + true-peak only (configs[1] chain)")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path: gloo ranks and a stub engine; not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become the launcher (nothing has touched a GPU yet)
+        if not args.stub_engine:
+            visible = torch.cuda.device_count()  # does not initialise HIP on this image
+            if visible < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) are visible; refusing to print a "
+                                 f"line for fewer ranks than asked for")
+        raise SystemExit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     distributed = world > 1
-    if args.gpus != world and distributed:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself; under torchrun pass --nproc-per-node N)")
+    if args.stub_engine:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        if args.stub_engine:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.variant:
         os.environ["AF_KERNEL_VARIANT"] = args.variant
@@ -184,6 +255,8 @@ def main() -> None:
     streams = args.streams
     first_stream, shard = sharding.stream_shard(world * streams, rank, world)  # weak scaling: B/G fixed per GPU
     assert shard == streams
+    if args.stub_engine:
+        return run_stub(args, world, rank, streams, n, first_stream)
     x = synth_batch(streams, n_blocks, first_stream, device)
     y = torch.empty_like(x)
     torch.cuda.synchronize()
@@ -291,6 +364,42 @@ def main() -> None:
         print(json.dumps(line))
     engine.close()
     if distributed:
+        dist.destroy_process_group()
+
+
+def run_stub(args, world: int, rank: int, streams: int, n: int, first_stream: int) -> None:
+    """The launch path with a stub engine on CPU (gloo): same barrier / timing / reduction code, no kernels."""
+    import torch.distributed as dist
+
+    from mic_eq_mi import sharding
+
+    engine = StubEngine(streams, n, first_stream)
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        engine.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sums, maxes = sharding.local_metrics(engine.rows, streams * n * args.steps, elapsed)
+    merged = sharding.reduce_metrics(sums, maxes, torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain", "stub": True,
+            "value": merged["samples"] / merged["elapsed_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": merged["elapsed_s"] / args.steps * 1000.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "STUB ENGINE (launch-path rehearsal on CPU, not a measurement)", "streams_per_gpu": streams,
+                       "sharding": f"streams x{world}, no data-path collective"},
+            "checks": {"total_samples": int(merged["samples"]), "input_square_sum": merged["input_square_sum"]},
+        }))
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -119,8 +119,9 @@ int af_engine_set_input_clamp_enabled(af_engine *e, int32_t enabled);
 int af_engine_set_prefilter_enabled(af_engine *e, int32_t enabled, int32_t apply_fixed_highpass);
 
 /* ---- RNNoise suppressor: rust-core/src/dsp/rnnoise.rs (RNNoiseProcessor) -------------------------
- * Runs between the front end and the EQ (dsp_loop.rs:1521-1599).  48 kHz only; n_samples of every
- * process call must then be a multiple of 480 (one frame).  Output is delayed by one frame
+ * Runs between the front end and the EQ (dsp_loop.rs:1521-1599).  48 kHz only.  The suppressor eats whole
+ * 480-sample frames: what a process call leaves over waits in the engine for the next call (rnnoise.rs:114-164), and a
+ * call returns floor((pending + n) / 480) * 480 samples per stream (see af_engine_stream_host below).  Output is delayed by one frame
  * (latency_samples() = 480, rnnoise.rs:313-315).  The network weights of nnnoiseless 0.5.2 are not
  * available offline: engines start on seeded synthetic weights in the real layout; load the real
  * ones with af_suppressor_load_weights (blob = the model's fifteen int8 arrays: input_dense w,b;
@@ -132,6 +133,13 @@ int af_suppressor_load_weights(af_engine *e, const int8_t *blob, size_t bytes);
 /* 1: the file protocol of bin/rnnoise_benchmark.rs:51-117 (clamp(+-1)*32768 in, /32768 out, no mix) */
 int af_suppressor_set_raw_protocol(af_engine *e, int32_t enabled);
 int32_t af_suppressor_latency_samples(const af_engine *e);
+/* test tap: RNNoiseProcessor::scale_sample_for_model (rnnoise.rs:89-111; pinned by rnnoise.rs:335-352) evaluated
+ * element-wise by the device function the pre-pass kernel uses; host pointers */
+int af_suppressor_debug_scale_for_model(const float *in, float *out, int64_t n, int32_t device);
+/* test tap: (silence flag, pitch index) of every frame of the last process call, [frame][stream][2] int32 */
+int af_suppressor_set_trace_enabled(af_engine *e, int32_t enabled);
+int64_t af_suppressor_trace_frames(const af_engine *e);
+int af_suppressor_read_trace(af_engine *e, int32_t *out, int64_t capacity_frames);
 /* test tap: the analysis record (158 floats/ints) and spectra X, P (481 complex each) of one
  * (frame, stream) cell of the last suppressor window */
 int af_suppressor_debug_read(af_engine *e, int32_t frame, int32_t stream, float *record, float *x_spectrum,
@@ -202,6 +210,15 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
 int af_engine_process_host(af_engine *e, const float *in, float *out, int64_t n_samples,
                            int32_t layout);
 int af_engine_synchronize(af_engine *e);
+/* One wake-up of the realtime loop with the suppressor on (dsp_loop.rs:1521-1599: push_samples -> process_frames ->
+ * pop_samples_into -> downstream chain): n_in new samples per stream go in ([stream][n_in]), the whole 480-sample frames
+ * that are complete come out (*n_out = floor((pending + n_in) / 480) * 480 per stream at out_stride, possibly 0 or more
+ * than n_in), the remainder waits in the engine.  af_engine_process_* follow the same rule (af_engine_process_device
+ * needs stream_stride >= that count; af_engine_process_host fails when it exceeds n_samples).  Without the suppressor
+ * *n_out == n_in.  Reference test: rnnoise.rs:355-370 (400 in -> 0 out, 400 pending; +100 -> 480 out, 20 pending). */
+int af_engine_stream_host(af_engine *e, const float *in, int64_t n_in, float *out, int64_t out_stride, int64_t *n_out);
+int64_t af_engine_pending_input(const af_engine *e);        /* RNNoiseProcessor::pending_input, rnnoise.rs:234-237 */
+int64_t af_engine_last_output_samples(const af_engine *e);  /* samples per stream the last process call produced */
 /* Blocks produced by the last process call and their stats, row-major [block][stream]
  * (synchronises).  `capacity` is in rows of af_block_stats. */
 int64_t af_engine_last_block_count(const af_engine *e);
@@ -296,6 +313,42 @@ int af_measure_integrated_loudness_device(const float *d_audio, int64_t n_sample
 int af_measure_integrated_loudness_host(const float *audio, int64_t n_samples, int32_t n_streams,
                                         int64_t stream_stride, uint32_t sample_rate, int32_t device,
                                         double *lufs, int32_t *status);
+
+/* ---- NoiseSuppressor: rust-core/src/dsp/noise_suppressor.rs:18-194 ----------------------------------------
+ * The runtime-selected suppressor interface (`NoiseModel`, trait `NoiseSuppressor`, `new_noise_suppression_engine`) for a
+ * batch of streams that advance in lock step: sample counts are per stream, audio is [stream][stride] host memory, the
+ * two fixed rings hold 8192 + 480 samples per stream (rnnoise.rs:11).  Model ids as NoiseModel::from_id / id(); the
+ * DeepFilterNet variants parse but cannot be created (AF_ERR_UNSUPPORTED: the reference loads them from a runtime
+ * library + model archives that are not in its checkout, deepfilter_ffi.rs:9-16), and af_noise_model_available lists
+ * what a default build of the reference lists: RNNoise. */
+enum { AF_NOISE_MODEL_RNNOISE = 0, AF_NOISE_MODEL_DEEPFILTER_LL = 1, AF_NOISE_MODEL_DEEPFILTER = 2 };
+typedef struct af_noise_suppressor af_noise_suppressor;
+int af_noise_model_from_id(const char *id, int32_t *model);           /* noise_suppressor.rs:58-67 */
+const char *af_noise_model_id(int32_t model);                         /* noise_suppressor.rs:47-55; VALUE */
+const char *af_noise_model_display_name(int32_t model);               /* noise_suppressor.rs:36-44; VALUE */
+int32_t af_noise_model_available(int32_t *models, int32_t capacity);  /* noise_suppressor.rs:70-84; VALUE: count */
+int af_noise_suppressor_create(int32_t model, int32_t n_streams, int32_t device, af_noise_suppressor **out); /* :168-194 */
+void af_noise_suppressor_destroy(af_noise_suppressor *s);
+/* the engine behind it (weights: af_suppressor_load_weights / af_suppressor_set_synthetic_weights before the first frame) */
+af_engine *af_noise_suppressor_engine(af_noise_suppressor *s);
+/* VALUE functions: sample counts per stream (negative af_status on a bad argument) */
+int64_t af_noise_suppressor_push_samples(af_noise_suppressor *s, const float *samples, int64_t n, int64_t stride);
+int af_noise_suppressor_process_frames(af_noise_suppressor *s);
+int64_t af_noise_suppressor_available_samples(const af_noise_suppressor *s);
+int64_t af_noise_suppressor_pending_input(const af_noise_suppressor *s);
+int64_t af_noise_suppressor_pop_samples_into(af_noise_suppressor *s, float *out, int64_t count, int64_t stride);
+int64_t af_noise_suppressor_drain_pending_input(af_noise_suppressor *s, float *out, int64_t capacity, int64_t stride);
+int af_noise_suppressor_set_strength(af_noise_suppressor *s, float value);   /* clamps to [0, 1] */
+float af_noise_suppressor_get_strength(const af_noise_suppressor *s);        /* VALUE */
+int af_noise_suppressor_set_enabled(af_noise_suppressor *s, int32_t enabled); /* disabled = bit-exact passthrough */
+int32_t af_noise_suppressor_is_enabled(const af_noise_suppressor *s);        /* VALUE */
+int af_noise_suppressor_soft_reset(af_noise_suppressor *s);                  /* rings cleared, model state kept */
+int af_noise_suppressor_reset(af_noise_suppressor *s);                       /* rnnoise.rs:205-210 */
+int32_t af_noise_suppressor_model_type(const af_noise_suppressor *s);        /* VALUE */
+int32_t af_noise_suppressor_latency_samples(const af_noise_suppressor *s);   /* VALUE: 480 */
+int32_t af_noise_suppressor_backend_available(const af_noise_suppressor *s); /* VALUE */
+int32_t af_noise_suppressor_backend_failed(const af_noise_suppressor *s);    /* VALUE */
+const char *af_noise_suppressor_backend_error(const af_noise_suppressor *s); /* VALUE: NULL = none */
 
 /* ---- stateless helpers ----------------------------------------------------------- */
 /* eq_magnitude_response, lib.rs:99-150 (legacy (freq, gain_db, q) x 10 bands) */

@@ -400,6 +400,108 @@ def suppressor_process(audio, strength: float = 1.0, weight_seed: int = 0x5EED) 
     return out[:n]
 
 
+def set_rnn_eval_order(order: int) -> None:
+    """0 = wavefront-native sums (what the GPU evaluates), 1 = the published scalar C's running sums (af_rnnoise.c)."""
+    C.c_int.in_dll(lib(), "afo_rnn_eval_order").value = int(order)
+
+
+def suppressor_process_traced(audio, strength: float = 1.0, weight_seed: int = 0x5EED, eval_order: int = 0):
+    """suppressor_process plus the per-frame (pitch index, silence flag) decisions; `eval_order` as set_rnn_eval_order."""
+    audio = np.ascontiguousarray(audio, dtype=np.float32)
+    L = lib()
+    L.afo_suppressor_process_traced.restype = C.c_size_t
+    L.afo_suppressor_process_traced.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t,
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    state = C.create_string_buffer(1 << 18)
+    L.afo_suppressor_init(state, float(strength), C.c_uint64(weight_seed))
+    frames = audio.size // 480
+    out = np.zeros_like(audio)
+    pitch = np.zeros(frames, dtype=np.int32)
+    silence = np.zeros(frames, dtype=np.int32)
+    set_rnn_eval_order(eval_order)
+    try:
+        n = L.afo_suppressor_process_traced(state, _fptr(out), _fptr(audio), audio.size,
+                                            pitch.ctypes.data_as(C.POINTER(C.c_int32)), silence.ctypes.data_as(C.POINTER(C.c_int32)))
+    finally:
+        set_rnn_eval_order(0)
+    return out[:n], pitch, silence
+
+
+def scale_sample_for_model(sample: float) -> float:
+    """RNNoiseProcessor::scale_sample_for_model (rnnoise.rs:89-111)."""
+    L = lib()
+    L.afo_scale_sample_for_model.restype = C.c_float
+    L.afo_scale_sample_for_model.argtypes = [C.c_float]
+    return float(L.afo_scale_sample_for_model(C.c_float(sample)))
+
+
+class RNNoiseProcessor:
+    """The reference's RNNoiseProcessor surface (rnnoise.rs:25-245) over the restatement, rings included."""
+
+    def __init__(self, strength: float = 1.0, weight_seed: int = 0x5EED):
+        L = lib()
+        sz, vp, fp = C.c_size_t, C.c_void_p, C.POINTER(C.c_float)
+        L.afo_processor_init.argtypes = [vp, C.c_float, C.c_uint64]
+        L.afo_processor_set_strength.argtypes = [vp, C.c_float]
+        L.afo_processor_get_strength.restype = C.c_float
+        L.afo_processor_get_strength.argtypes = [vp]
+        L.afo_processor_push_samples.restype = sz
+        L.afo_processor_push_samples.argtypes = [vp, fp, sz]
+        L.afo_processor_process_frames.argtypes = [vp]
+        for name in ("available_samples", "pending_input"):
+            fn = getattr(L, f"afo_processor_{name}")
+            fn.restype = sz
+            fn.argtypes = [vp]
+        for name in ("read_samples", "drain_pending_input"):
+            fn = getattr(L, f"afo_processor_{name}")
+            fn.restype = sz
+            fn.argtypes = [vp, fp, sz]
+        L.afo_processor_set_enabled.argtypes = [vp, C.c_int]
+        L.afo_processor_soft_reset.argtypes = [vp]
+        L.afo_processor_reset.argtypes = [vp]
+        self._L = L
+        self._p = C.create_string_buffer(1 << 18)  # afo_rnnoise_processor is ~210 KB
+        L.afo_processor_init(self._p, float(strength), C.c_uint64(weight_seed))
+
+    def set_strength(self, v: float) -> None:
+        self._L.afo_processor_set_strength(self._p, float(v))
+
+    def get_strength(self) -> float:
+        return float(self._L.afo_processor_get_strength(self._p))
+
+    def push_samples(self, samples) -> int:
+        a = np.ascontiguousarray(samples, dtype=np.float32)
+        return int(self._L.afo_processor_push_samples(self._p, _fptr(a), a.size))
+
+    def process_frames(self) -> None:
+        self._L.afo_processor_process_frames(self._p)
+
+    def available_samples(self) -> int:
+        return int(self._L.afo_processor_available_samples(self._p))
+
+    def pending_input(self) -> int:
+        return int(self._L.afo_processor_pending_input(self._p))
+
+    def read_samples(self, count: int) -> np.ndarray:
+        out = np.zeros(int(count), dtype=np.float32)
+        n = int(self._L.afo_processor_read_samples(self._p, _fptr(out), out.size))
+        return out[:n]
+
+    def drain_pending_input(self) -> np.ndarray:
+        out = np.zeros(8192 + 480, dtype=np.float32)
+        n = int(self._L.afo_processor_drain_pending_input(self._p, _fptr(out), out.size))
+        return out[:n]
+
+    def set_enabled(self, on: bool) -> None:
+        self._L.afo_processor_set_enabled(self._p, int(bool(on)))
+
+    def soft_reset(self) -> None:
+        self._L.afo_processor_soft_reset(self._p)
+
+    def reset(self) -> None:
+        self._L.afo_processor_reset(self._p)
+
+
 def prefilter(audio, sample_rate: float = 48000.0) -> np.ndarray:
     """DC block + 80 Hz high-pass (routing.rs:826-843)."""
     class Pre(C.Structure):

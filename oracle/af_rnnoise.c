@@ -125,6 +125,23 @@ static void apply_window(float *x) {
  * block is summed left to right, and the block sums are added in block order.  The scalar C of RNNoise uses
  * one running accumulator per band; this differs from it only in the last roundings. */
 static void band_accumulate(float *bandE, const cpx *X, const cpx *P) {
+  if (afo_rnn_eval_order == 1) { /* compute_band_energy / compute_band_corr of the published C: one accumulator per band */
+    float sum[NB] = {0};
+    for (int i = 0; i < NB - 1; ++i) {
+      int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
+      for (int j = 0; j < band_size; ++j) {
+        float frac = (float)j / band_size;
+        int idx = (eband5ms[i] << 2) + j;
+        float tmp = X[idx].r * P[idx].r + X[idx].i * P[idx].i;
+        sum[i] += (1 - frac) * tmp;
+        sum[i + 1] += frac * tmp;
+      }
+    }
+    sum[0] *= 2;
+    sum[NB - 1] *= 2;
+    memcpy(bandE, sum, sizeof sum);
+    return;
+  }
   float rise[NB] = {0}, fall[NB] = {0};
   for (int i = 0; i < NB - 1; ++i) {
     int band_size = (eband5ms[i + 1] - eband5ms[i]) << 2;
@@ -181,7 +198,21 @@ static void dct(float *out, const float *in) {
  *                   a lane, Hillis-Steele inclusive scan of the 64 lane totals, one add of the offset.
  * The short lag-parallel correlations (coarse pitch search) keep the plain left-to-right order, each term one fused
  * multiply-add (inner_prod_fma): that is what a matrix-core instruction evaluates, and the GPU runs them there. */
+/* afo_rnn_eval_order: 0 = the wavefront-native order described above (what the GPU kernels evaluate);
+ * 1 = the order of the published scalar C (one running accumulator, left to right, unfused multiply-add; band sums with one
+ * accumulator per band; the yy table as a running sum).  Order 1 is implementation-independent: tests hold both the GPU and
+ * order 0 against it and count the frames whose pitch decision differs (the crate itself is absent, so neither is "the"
+ * reference order -- see the parity note at the top). */
+int afo_rnn_eval_order = 0;
+
+static float dot_seq(const float *x, const float *y, int n) {
+  float s = 0;
+  for (int i = 0; i < n; ++i) s = s + x[i] * y[i];
+  return s;
+}
+
 static float dot64(const float *x, const float *y, int n) {
+  if (afo_rnn_eval_order == 1) return dot_seq(x, y, n);
   float p[64];
   for (int l = 0; l < 64; ++l) {
     float acc = 0.0f;
@@ -198,6 +229,11 @@ static float dot64(const float *x, const float *y, int n) {
 
 /* out[i] = e[0] + ... + e[i] for i < n (n <= 64 * 8) in the blocked order described above */
 static void scan64(const float *e, float *out, int n) {
+  if (afo_rnn_eval_order == 1) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) { acc = acc + e[i]; out[i] = acc; }
+    return;
+  }
   const int chunk = (n + 63) / 64;
   float total[64], local[512];
   for (int l = 0; l < 64; ++l) {
@@ -230,6 +266,10 @@ static float inner_prod_fma(const float *x, const float *y, int n) {
 }
 
 static void pitch_xcorr(const float *x, const float *y, float *xcorr, int len, int max_pitch) {
+  if (afo_rnn_eval_order == 1) {
+    for (int i = 0; i < max_pitch; ++i) xcorr[i] = dot_seq(x, y + i, len);
+    return;
+  }
   for (int i = 0; i < max_pitch; ++i) xcorr[i] = inner_prod_fma(x, y + i, len);
 }
 
@@ -352,8 +392,16 @@ static float remove_doubling(const float *x, int maxperiod, int minperiod, int N
   {
     float e[PMAX >> 1], S[PMAX >> 1];
     for (int i = 1; i <= maxperiod; ++i) e[i - 1] = x[-i] * x[-i] - x[N - i] * x[N - i];
-    scan64(e, S, maxperiod);
-    for (int i = 1; i <= maxperiod; ++i) yy_lookup[i] = fmaxf(0, xx + S[i - 1]);
+    if (afo_rnn_eval_order == 1) { /* yy = yy + x[-i]^2 - x[N-i]^2, running */
+      float yy_run = xx;
+      for (int i = 1; i <= maxperiod; ++i) {
+        yy_run = yy_run + x[-i] * x[-i] - x[N - i] * x[N - i];
+        yy_lookup[i] = fmaxf(0, yy_run);
+      }
+    } else {
+      scan64(e, S, maxperiod);
+      for (int i = 1; i <= maxperiod; ++i) yy_lookup[i] = fmaxf(0, xx + S[i - 1]);
+    }
   }
   float yy = yy_lookup[T0];
   float best_xy = xy, best_yy = yy;
@@ -659,7 +707,7 @@ void afo_suppressor_init(afo_suppressor *s, float strength, uint64_t weight_seed
 }
 
 /* rnnoise.rs:89-111 */
-static float scale_sample_for_model(float sample) {
+float afo_scale_sample_for_model(float sample) {
   const float PCM_SCALE = 32768.0f, LIMIT = 32760.0f, LIMIT_UNIT = 32760.0f / 32768.0f, THR = 0.98f;
   const float KNEE = 1.0f - 0.98f;
   float v;
@@ -682,7 +730,7 @@ static float scale_sample_for_model(float sample) {
 /* one 480-sample frame of RNNoiseProcessor::process_frames (rnnoise.rs:122-164) */
 void afo_suppressor_process_frame(afo_suppressor *s, float *out, const float *dry) {
   float scaled[FRAME], wet[FRAME];
-  for (int i = 0; i < FRAME; ++i) scaled[i] = scale_sample_for_model(dry[i]);
+  for (int i = 0; i < FRAME; ++i) scaled[i] = afo_scale_sample_for_model(dry[i]);
   afo_rnn_process_frame(&s->w, &s->st, wet, scaled);
   for (int i = 0; i < FRAME; ++i) wet[i] /= 32768.0f;
   s->smoothed_strength = s->strength * s->smoothing_coeff + s->smoothed_strength * (1.0f - s->smoothing_coeff);
@@ -697,6 +745,17 @@ void afo_suppressor_process_frame(afo_suppressor *s, float *out, const float *dr
 size_t afo_suppressor_process(afo_suppressor *s, float *out, const float *in, size_t n) {
   size_t frames = n / FRAME;
   for (size_t f = 0; f < frames; ++f) afo_suppressor_process_frame(s, out + f * FRAME, in + f * FRAME);
+  return frames * FRAME;
+}
+
+/* the same with the per-frame pitch decision and silence flag recorded (tests count differing decisions) */
+size_t afo_suppressor_process_traced(afo_suppressor *s, float *out, const float *in, size_t n, int32_t *pitch, int32_t *silence) {
+  size_t frames = n / FRAME;
+  for (size_t f = 0; f < frames; ++f) {
+    afo_suppressor_process_frame(s, out + f * FRAME, in + f * FRAME);
+    if (pitch) pitch[f] = afo_rnn_last.pitch_index;
+    if (silence) silence[f] = afo_rnn_last.silence;
+  }
   return frames * FRAME;
 }
 
@@ -718,4 +777,81 @@ void afo_rnnoise_benchmark_frames(const float *in, float *out, size_t n, uint64_
     afo_rnn_process_frame(&w, &st, frame_out, frame_in);
     for (size_t i = 0; i < len; ++i) out[start + i] = frame_out[i] / 32768.0f;
   }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * RNNoiseProcessor with its two fixed rings (rnnoise.rs:11,25-42,114-245 over audio/rt.rs:146-248):
+ * push_samples -> process_frames -> pop / read, pending_input, set_enabled (bypass moves the input
+ * ring to the output ring untouched), soft_reset (= flush_buffers), reset. */
+static size_t ring_remaining(const afo_ring *r) { return AFO_RNN_RING_CAPACITY - r->len; }
+static void ring_clear(afo_ring *r) { r->head = 0; r->len = 0; }
+static size_t ring_push_slice(afo_ring *r, const float *v, size_t n) { /* rt.rs:189-197 */
+  size_t written = n < ring_remaining(r) ? n : ring_remaining(r);
+  for (size_t k = 0; k < written; ++k) r->data[(r->head + r->len + k) % AFO_RNN_RING_CAPACITY] = v[k];
+  r->len += written;
+  return written;
+}
+static size_t ring_pop_into(afo_ring *r, float *out, size_t n) { /* rt.rs:209-221 */
+  size_t count = n < r->len ? n : r->len;
+  for (size_t k = 0; k < count; ++k) out[k] = r->data[(r->head + k) % AFO_RNN_RING_CAPACITY];
+  r->head = (r->head + count) % AFO_RNN_RING_CAPACITY;
+  r->len -= count;
+  if (r->len == 0) r->head = 0;
+  return count;
+}
+static size_t ring_move_into(afo_ring *from, afo_ring *to) { /* rt.rs:223-235 */
+  size_t moved = 0;
+  float scratch[64];
+  while (from->len > 0 && ring_remaining(to) > 0) {
+    size_t count = from->len;
+    if (count > ring_remaining(to)) count = ring_remaining(to);
+    if (count > 64) count = 64;
+    size_t popped = ring_pop_into(from, scratch, count);
+    if (popped == 0) break;
+    moved += ring_push_slice(to, scratch, popped);
+  }
+  return moved;
+}
+
+void afo_processor_init(afo_rnnoise_processor *p, float strength, uint64_t weight_seed) {
+  memset(p, 0, sizeof(*p));
+  afo_suppressor_init(&p->core, strength, weight_seed);
+  p->enabled = 1; /* rnnoise.rs:58 */
+}
+void afo_processor_set_strength(afo_rnnoise_processor *p, float v) { /* rnnoise.rs:67-72 */
+  p->core.strength = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+float afo_processor_get_strength(const afo_rnnoise_processor *p) { return p->core.strength; }
+size_t afo_processor_push_samples(afo_rnnoise_processor *p, const float *v, size_t n) { return ring_push_slice(&p->input, v, n); }
+void afo_processor_process_frames(afo_rnnoise_processor *p) { /* rnnoise.rs:122-164 */
+  if (!p->enabled) {
+    ring_move_into(&p->input, &p->output);
+    return;
+  }
+  float dry[FRAME], out[FRAME];
+  while (p->input.len >= FRAME && ring_remaining(&p->output) >= FRAME) {
+    if (ring_pop_into(&p->input, dry, FRAME) != FRAME) break;
+    afo_suppressor_process_frame(&p->core, out, dry);
+    ring_push_slice(&p->output, out, FRAME);
+  }
+}
+size_t afo_processor_available_samples(const afo_rnnoise_processor *p) { return p->output.len; }
+size_t afo_processor_pending_input(const afo_rnnoise_processor *p) { return p->input.len; }
+size_t afo_processor_read_samples(afo_rnnoise_processor *p, float *out, size_t n) { /* rnnoise.rs:185-188 */
+  size_t count = n < p->output.len ? n : p->output.len;
+  return ring_pop_into(&p->output, out, count);
+}
+size_t afo_processor_drain_pending_input(afo_rnnoise_processor *p, float *out, size_t cap) { /* rnnoise.rs:240-244 */
+  size_t count = cap < p->input.len ? cap : p->input.len;
+  return ring_pop_into(&p->input, out, count);
+}
+void afo_processor_set_enabled(afo_rnnoise_processor *p, int on) { p->enabled = on != 0; }
+void afo_processor_soft_reset(afo_rnnoise_processor *p) { /* rnnoise.rs:216-232 */
+  ring_clear(&p->input);
+  ring_clear(&p->output);
+}
+void afo_processor_reset(afo_rnnoise_processor *p) { /* rnnoise.rs:205-210: DenoiseState::new(), smoothing state kept */
+  afo_rnn_state_init(&p->core.st);
+  ring_clear(&p->input);
+  ring_clear(&p->output);
 }

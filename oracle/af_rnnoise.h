@@ -57,7 +57,38 @@ typedef struct {
 void afo_suppressor_init(afo_suppressor *s, float strength, uint64_t weight_seed);
 void afo_suppressor_process_frame(afo_suppressor *s, float *out, const float *dry);
 size_t afo_suppressor_process(afo_suppressor *s, float *out, const float *in, size_t n);
+size_t afo_suppressor_process_traced(afo_suppressor *s, float *out, const float *in, size_t n, int32_t *pitch, int32_t *silence);
 void afo_rnnoise_benchmark_frames(const float *in, float *out, size_t n, uint64_t weight_seed);
+
+
+/* evaluation order of the long sums: 0 = wavefront-native (the GPU's), 1 = published scalar C (see af_rnnoise.c) */
+extern int afo_rnn_eval_order;
+/* RNNoiseProcessor::scale_sample_for_model (rnnoise.rs:89-111) */
+float afo_scale_sample_for_model(float sample);
+
+/* RNNoiseProcessor with its fixed rings (rnnoise.rs:11: capacity 8192 + 480) */
+#define AFO_RNN_RING_CAPACITY (8192 + 480)
+typedef struct {
+  float data[AFO_RNN_RING_CAPACITY];
+  size_t head, len;
+} afo_ring;
+typedef struct {
+  afo_suppressor core;
+  afo_ring input, output;
+  int enabled;
+} afo_rnnoise_processor;
+void afo_processor_init(afo_rnnoise_processor *p, float strength, uint64_t weight_seed);
+void afo_processor_set_strength(afo_rnnoise_processor *p, float v);
+float afo_processor_get_strength(const afo_rnnoise_processor *p);
+size_t afo_processor_push_samples(afo_rnnoise_processor *p, const float *v, size_t n);
+void afo_processor_process_frames(afo_rnnoise_processor *p);
+size_t afo_processor_available_samples(const afo_rnnoise_processor *p);
+size_t afo_processor_pending_input(const afo_rnnoise_processor *p);
+size_t afo_processor_read_samples(afo_rnnoise_processor *p, float *out, size_t n);
+size_t afo_processor_drain_pending_input(afo_rnnoise_processor *p, float *out, size_t cap);
+void afo_processor_set_enabled(afo_rnnoise_processor *p, int on);
+void afo_processor_soft_reset(afo_rnnoise_processor *p);
+void afo_processor_reset(afo_rnnoise_processor *p);
 
 #ifdef __cplusplus
 }

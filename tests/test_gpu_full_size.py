@@ -27,7 +27,7 @@ def run():
     x = bench.synth_batch(STREAMS, SECONDS * 100, 0, dev)
     n = x.shape[1]
 
-    def process(full_chain: bool, streams=slice(None)):
+    def process(full_chain: bool, streams=slice(None), trace: bool = False):
         xin = x[streams].contiguous()
         y = torch.empty_like(xin)
         eng = core.Engine(48_000.0, xin.shape[0], 0)
@@ -35,11 +35,13 @@ def run():
         if full_chain:
             eng.set_prefilter_enabled(1, 1)
             eng.set_suppressor_enabled(1)
+            eng.suppressor_set_trace_enabled(int(trace))
         eng.process_device(xin.data_ptr(), y.data_ptr(), n, n, 0, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         rows = eng.block_stats()
+        decisions = eng.suppressor_trace() if (full_chain and trace) else None
         eng.close()
-        return y, rows
+        return (y, rows, decisions) if trace else (y, rows)
 
     return x, process
 
@@ -51,7 +53,7 @@ def test_full_size_properties(run, oracle, full_chain):
     import bench
 
     x, process = run
-    y, rows = process(full_chain)
+    y, rows, decisions = process(full_chain, trace=True)
     assert bool(torch.isfinite(y).all())
     # determinism: a second engine over the same input gives the same bits
     y2, _ = process(full_chain)
@@ -66,11 +68,27 @@ def test_full_size_properties(run, oracle, full_chain):
     direct = (y.double() ** 2).sum(dim=1).cpu().numpy()
     assert np.allclose(out_sq, direct, rtol=1e-9)
     assert rows.shape == (SECONDS * 50, STREAMS)
-    # sampled streams against the CPU oracle
-    for s in (0, 1000, 4095):
+    # 64 streams spread over every part of the batch (workgroups of 64, network tiles of 16, both ends) against the CPU
+    # oracle; with the suppressor on, every frame's pitch decision and silence flag is compared too and the number of
+    # differing decisions is reported and bounded (a differing decision is a near-tie resolved the other way)
+    sample = sorted({0, 1, 15, 16, 63, 64, 1000, 2047, 2048, 4032, 4080, 4095} | {int(v) for v in np.linspace(0, STREAMS - 1, 56)})
+    assert len(sample) >= 64
+    worst_rms, flips, frames = 0.0, 0, 0
+    for s in sample:
         xs = x[s].cpu().numpy()
-        ref_in = oracle.suppressor_process(oracle.prefilter(xs), 1.0) if full_chain else xs
+        if full_chain:
+            ref_in, pitch, silence = oracle.suppressor_process_traced(oracle.prefilter(xs), 1.0)
+            assert np.array_equal(decisions[:, s, 0], silence), s
+            flips += int(np.count_nonzero(decisions[:, s, 1] != pitch))
+            frames += pitch.size
+        else:
+            ref_in = xs
         want = oracle.simulate_auto_eq_chain(ref_in, 48_000, bench.BANDS, dict(bench.CHAIN_SETTINGS, return_output_audio=True))["output_audio"]
         d = y[s].cpu().numpy().astype(np.float64) - want.astype(np.float64)
         rms = float(np.sqrt(np.mean(d * d)))
+        worst_rms = max(worst_rms, rms)
         assert rms <= (1e-5 if full_chain else 2e-8), (s, rms)
+    print(f"full size ({'full' if full_chain else 'dynamics'} chain): {len(sample)} streams vs oracle, worst RMS {worst_rms:.3e}, "
+          f"pitch decisions differing: {flips} of {frames} frames")
+    if full_chain:
+        assert flips <= frames // 1000

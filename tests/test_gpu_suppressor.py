@@ -109,11 +109,13 @@ def test_front_end_then_suppressor(mi, oracle):
     _check(got, want)
 
 
-def test_frame_multiple_is_required(mi):
+def test_a_ragged_call_returns_whole_frames(mi):
+    """rnnoise.rs:114-164: 500 samples in -> one frame out, 20 samples wait (tests/test_gpu_noise_suppressor.py holds the
+    reference's own counts)."""
     eng = mi.Engine(48_000.0, 1)
     eng.set_suppressor_enabled(1)
-    with pytest.raises(ValueError, match="multiple of 480"):
-        eng.process(np.zeros((1, 500), dtype=np.float32))
+    out = eng.process(np.zeros((1, 500), dtype=np.float32))
+    assert out.shape == (1, 480) and eng.pending_input() == 20
     eng.close()
 
 
