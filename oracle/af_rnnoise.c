@@ -94,7 +94,102 @@ static void fft_rec(const cpx *in, cpx *out, int n, int stride) {
   }
 }
 
+/* ---- timed path (afo_rnn_fft_mode = 1): the same transforms as a 480-point complex mixed-radix FFT (4.4.2.3.5, decimation
+ * in time, twiddles from the table above) over the even/odd packing of the real window.  The checker path above stays
+ * what the parity tests were taken with; this one exists so that the CPU baseline of bench.py is not handicapped by a
+ * plain recursive transform (results differ from the checker path in the last bits only: tests/test_oracle_rnnoise_wrapper.py). */
+int afo_rnn_fft_mode = 0;
+#define HALF 480
+static const int fast_radix[5] = {4, 4, 2, 3, 5};
+
+/* out[k], k < n: DFT of in[0], in[stride], ... (n = product of radix[0..]); recursion depth 5, no scratch */
+static void fast_fft_rec(cpx *out, const cpx *in, int n, int stride, const int *radix) {
+  const int p = radix[0], m = n / p;
+  if (m == 1) {
+    for (int q = 0; q < p; ++q) out[q] = in[q * stride];
+  } else {
+    for (int q = 0; q < p; ++q) fast_fft_rec(out + q * m, in + q * stride, m, stride * p, radix + 1);
+  }
+  const int tw_step = WINDOW / n; /* W_n^j = tw[j * 960 / n] */
+  for (int k = 0; k < m; ++k) {
+    cpx t[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int q = 0; q < p; ++q) {
+      const cpx v = out[q * m + k];
+      const int ti = q * k * tw_step;
+      const float wr = tw_re[ti], wi = tw_im[ti];
+      t[q].r = v.r * wr - v.i * wi;
+      t[q].i = v.r * wi + v.i * wr;
+    }
+    if (p == 2) {
+      out[k].r = t[0].r + t[1].r; out[k].i = t[0].i + t[1].i;
+      out[k + m].r = t[0].r - t[1].r; out[k + m].i = t[0].i - t[1].i;
+    } else if (p == 4) {
+      const float ar = t[0].r + t[2].r, ai = t[0].i + t[2].i, br = t[0].r - t[2].r, bi = t[0].i - t[2].i;
+      const float cr = t[1].r + t[3].r, ci = t[1].i + t[3].i, dr = t[1].r - t[3].r, di = t[1].i - t[3].i;
+      out[k].r = ar + cr; out[k].i = ai + ci;
+      out[k + m].r = br + di; out[k + m].i = bi - dr;           /* b - i d */
+      out[k + 2 * m].r = ar - cr; out[k + 2 * m].i = ai - ci;
+      out[k + 3 * m].r = br - di; out[k + 3 * m].i = bi + dr;   /* b + i d */
+    } else if (p == 3) {
+      const float c = 0.86602540378443864676f;
+      const float sr = t[1].r + t[2].r, si = t[1].i + t[2].i, dr = t[1].r - t[2].r, di = t[1].i - t[2].i;
+      const float mr = t[0].r - 0.5f * sr, mi = t[0].i - 0.5f * si;
+      out[k].r = t[0].r + sr; out[k].i = t[0].i + si;
+      out[k + m].r = mr + c * di; out[k + m].i = mi - c * dr;
+      out[k + 2 * m].r = mr - c * di; out[k + 2 * m].i = mi + c * dr;
+    } else { /* 5 */
+      const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+      const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+      const float a1r = t[1].r + t[4].r, a1i = t[1].i + t[4].i, b1r = t[1].r - t[4].r, b1i = t[1].i - t[4].i;
+      const float a2r = t[2].r + t[3].r, a2i = t[2].i + t[3].i, b2r = t[2].r - t[3].r, b2i = t[2].i - t[3].i;
+      const float m1r = t[0].r + c1 * a1r + c2 * a2r, m1i = t[0].i + c1 * a1i + c2 * a2i;
+      const float m2r = t[0].r + c2 * a1r + c1 * a2r, m2i = t[0].i + c2 * a1i + c1 * a2i;
+      const float n1r = s1 * b1r + s2 * b2r, n1i = s1 * b1i + s2 * b2i;
+      const float n2r = s2 * b1r - s1 * b2r, n2i = s2 * b1i - s1 * b2i;
+      out[k].r = t[0].r + a1r + a2r; out[k].i = t[0].i + a1i + a2i;
+      out[k + m].r = m1r + n1i; out[k + m].i = m1i - n1r;           /* m1 - i n1 */
+      out[k + 4 * m].r = m1r - n1i; out[k + 4 * m].i = m1i + n1r;
+      out[k + 2 * m].r = m2r + n2i; out[k + 2 * m].i = m2i - n2r;
+      out[k + 3 * m].r = m2r - n2i; out[k + 3 * m].i = m2i + n2r;
+    }
+  }
+}
+
+static void fast_forward_transform(cpx *out /*FREQ*/, const float *in /*WINDOW*/) {
+  cpx z[HALF], Z[HALF];
+  for (int n = 0; n < HALF; ++n) { z[n].r = in[2 * n]; z[n].i = in[2 * n + 1]; }
+  fast_fft_rec(Z, z, HALF, 1, fast_radix);
+  const float s = 1.0f / WINDOW;
+  for (int k = 0; k <= HALF; ++k) {
+    const cpx a = Z[k % HALF], b = Z[(HALF - k) % HALF]; /* Z[k], Z[480 - k] */
+    const float er = 0.5f * (a.r + b.r), ei = 0.5f * (a.i - b.i);   /* even part: (Z[k] + conj Z[N-k]) / 2 */
+    const float orr = 0.5f * (a.i + b.i), oi = -0.5f * (a.r - b.r); /* odd part: (Z[k] - conj Z[N-k]) / (2 i) */
+    const float wr = tw_re[k % WINDOW], wi = tw_im[k % WINDOW];     /* W_960^k */
+    out[k].r = (er + (orr * wr - oi * wi)) * s;
+    out[k].i = (ei + (orr * wi + oi * wr)) * s;
+  }
+}
+
+static void fast_inverse_transform(float *out /*WINDOW*/, const cpx *in /*FREQ*/) {
+  /* x[2n] + i x[2n+1] = sum_k Z[k] W_480^{-kn},  Z[k] = (X[k] + X[k+480]) + i (X[k] - X[k+480]) W_960^{-k},
+   * X[k+480] = conj X[480-k]; the unscaled inverse runs through the forward kernel on conjugated input */
+  cpx Zc[HALF], z[HALF];
+  for (int k = 0; k < HALF; ++k) {
+    const cpx a = in[k], b = in[HALF - k];
+    const float sr = a.r + b.r, si = a.i - b.i;   /* X[k] + conj X[480-k] */
+    const float dr = a.r - b.r, di = a.i + b.i;   /* X[k] - conj X[480-k] */
+    const float wr = tw_re[k], wi = -tw_im[k];    /* W_960^{-k} */
+    const float tr = dr * wr - di * wi, ti = dr * wi + di * wr;
+    /* Z = s + i t; store conj(Z) */
+    Zc[k].r = sr - ti;
+    Zc[k].i = -(si + tr);
+  }
+  fast_fft_rec(z, Zc, HALF, 1, fast_radix);
+  for (int n = 0; n < HALF; ++n) { out[2 * n] = z[n].r; out[2 * n + 1] = -z[n].i; }
+}
+
 static void forward_transform(cpx *out /*FREQ*/, const float *in /*WINDOW*/) {
+  if (afo_rnn_fft_mode == 1) { fast_forward_transform(out, in); return; }
   cpx x[WINDOW], y[WINDOW];
   for (int i = 0; i < WINDOW; ++i) { x[i].r = in[i]; x[i].i = 0.0f; }
   fft_rec(x, y, WINDOW, 1);
@@ -103,6 +198,7 @@ static void forward_transform(cpx *out /*FREQ*/, const float *in /*WINDOW*/) {
 }
 
 static void inverse_transform(float *out /*WINDOW*/, const cpx *in /*FREQ*/) {
+  if (afo_rnn_fft_mode == 1) { fast_inverse_transform(out, in); return; }
   cpx x[WINDOW], y[WINDOW];
   for (int i = 0; i < FREQ; ++i) x[i] = in[i];
   for (int i = FREQ; i < WINDOW; ++i) { x[i].r = x[WINDOW - i].r; x[i].i = -x[WINDOW - i].i; }
@@ -197,7 +293,7 @@ static void dct(float *out, const float *in) {
  *   scan64(e, n):   prefix sums with each lane owning ceil(n/64) consecutive terms: sequential prefix inside
  *                   a lane, Hillis-Steele inclusive scan of the 64 lane totals, one add of the offset.
  * The short lag-parallel correlations (coarse pitch search) keep the plain left-to-right order, each term one fused
- * multiply-add (inner_prod_fma): that is what a matrix-core instruction evaluates, and the GPU runs them there. */
+ * multiply-add: that is what a matrix-core instruction evaluates, and the GPU runs them there. */
 /* afo_rnn_eval_order: 0 = the wavefront-native order described above (what the GPU kernels evaluate);
  * 1 = the order of the published scalar C (one running accumulator, left to right, unfused multiply-add; band sums with one
  * accumulator per band; the yy table as a running sum).  Order 1 is implementation-independent: tests hold both the GPU and
@@ -214,11 +310,11 @@ static float dot_seq(const float *x, const float *y, int n) {
 static float dot64(const float *x, const float *y, int n) {
   if (afo_rnn_eval_order == 1) return dot_seq(x, y, n);
   float p[64];
-  for (int l = 0; l < 64; ++l) {
-    float acc = 0.0f;
-    for (int i = l; i < n; i += 64) acc = acc + x[i] * y[i];
-    p[l] = acc;
-  }
+  for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+  int i0 = 0;
+  for (; i0 + 64 <= n; i0 += 64) /* p[l] takes its terms in ascending i either way; this loop order vectorises */
+    for (int l = 0; l < 64; ++l) p[l] = p[l] + x[i0 + l] * y[i0 + l];
+  for (int l = 0; i0 + l < n; ++l) p[l] = p[l] + x[i0 + l] * y[i0 + l];
   for (int off = 32; off >= 1; off >>= 1) {
     float q[64];
     for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
@@ -259,18 +355,16 @@ static void scan64(const float *e, float *out, int n) {
     }
 }
 
-static float inner_prod_fma(const float *x, const float *y, int n) {
-  float s = 0;
-  for (int i = 0; i < n; ++i) s = fmaf(x[i], y[i], s);
-  return s;
-}
-
 static void pitch_xcorr(const float *x, const float *y, float *xcorr, int len, int max_pitch) {
   if (afo_rnn_eval_order == 1) {
     for (int i = 0; i < max_pitch; ++i) xcorr[i] = dot_seq(x, y + i, len);
     return;
   }
-  for (int i = 0; i < max_pitch; ++i) xcorr[i] = inner_prod_fma(x, y + i, len);
+  for (int i = 0; i < max_pitch; ++i) xcorr[i] = 0.0f;
+  for (int j = 0; j < len; ++j) { /* every lag accumulates its terms in ascending j, one fused multiply-add each */
+    const float xj = x[j];
+    for (int i = 0; i < max_pitch; ++i) xcorr[i] = fmaf(xj, y[i + j], xcorr[i]);
+  }
 }
 
 static void celt_lpc4(float *lpc, const float *ac) {
@@ -459,36 +553,52 @@ static float tansig_approx(float x) {
 static float sigmoid_approx(float x) { return .5f + .5f * tansig_approx(.5f * x); }
 
 static void dense(const int8_t *w, const int8_t *bias, int n_in, int n_out, int act, float *out, const float *in) {
+  /* unit i accumulates bias, then its inputs in ascending j: the loops are interchanged (j outer) so that the units run
+   * side by side in vector lanes; the chain per unit is unchanged */
+  float sum[96];
+  for (int i = 0; i < n_out; ++i) sum[i] = bias[i];
+  for (int j = 0; j < n_in; ++j) {
+    const float v = in[j];
+    const int8_t *wr = w + j * n_out;
+    for (int i = 0; i < n_out; ++i) sum[i] = fmaf((float)wr[i], v, sum[i]);
+  }
   for (int i = 0; i < n_out; ++i) {
-    float sum = bias[i];
-    for (int j = 0; j < n_in; ++j) sum = fmaf((float)w[j * n_out + i], in[j], sum);
-    sum = WEIGHTS_SCALE * sum;
-    out[i] = act == 0 ? tansig_approx(sum) : sigmoid_approx(sum);
+    const float t = WEIGHTS_SCALE * sum[i];
+    out[i] = act == 0 ? tansig_approx(t) : sigmoid_approx(t);
   }
 }
 
 static void gru(const int8_t *w, const int8_t *u, const int8_t *bias, int M, int N, float *state, const float *in) {
-  float z[96], r[96], h[96];
+  float z[96], r[96], h[96], sum[96], gated[96];
   const int stride = 3 * N;
-  for (int i = 0; i < N; ++i) {
-    float sum = bias[i];
-    for (int j = 0; j < M; ++j) sum = fmaf((float)w[j * stride + i], in[j], sum);
-    for (int j = 0; j < N; ++j) sum = fmaf((float)u[j * stride + i], state[j], sum);
-    z[i] = sigmoid_approx(WEIGHTS_SCALE * sum);
-  }
-  for (int i = 0; i < N; ++i) {
-    float sum = bias[N + i];
-    for (int j = 0; j < M; ++j) sum = fmaf((float)w[N + i + j * stride], in[j], sum);
-    for (int j = 0; j < N; ++j) sum = fmaf((float)u[N + i + j * stride], state[j], sum);
-    r[i] = sigmoid_approx(WEIGHTS_SCALE * sum);
-  }
-  for (int i = 0; i < N; ++i) {
-    float sum = bias[2 * N + i];
-    for (int j = 0; j < M; ++j) sum = fmaf((float)w[2 * N + i + j * stride], in[j], sum);
-    for (int j = 0; j < N; ++j) sum = fmaf((float)u[2 * N + i + j * stride], state[j] * r[j], sum);
-    sum = WEIGHTS_SCALE * sum;
-    sum = sum < 0 ? 0 : sum; /* ReLU */
-    h[i] = z[i] * state[i] + (1 - z[i]) * sum;
+  /* per unit: bias, inputs in ascending j, recurrent inputs in ascending j (loops interchanged as in dense()) */
+  for (int gate = 0; gate < 3; ++gate) {
+    const int off = gate * N;
+    for (int i = 0; i < N; ++i) sum[i] = bias[off + i];
+    for (int j = 0; j < M; ++j) {
+      const float v = in[j];
+      const int8_t *wr = w + j * stride + off;
+      for (int i = 0; i < N; ++i) sum[i] = fmaf((float)wr[i], v, sum[i]);
+    }
+    const float *rec = gate == 2 ? gated : state;
+    if (gate == 2)
+      for (int j = 0; j < N; ++j) gated[j] = state[j] * r[j];
+    for (int j = 0; j < N; ++j) {
+      const float v = rec[j];
+      const int8_t *ur = u + j * stride + off;
+      for (int i = 0; i < N; ++i) sum[i] = fmaf((float)ur[i], v, sum[i]);
+    }
+    if (gate == 0) {
+      for (int i = 0; i < N; ++i) z[i] = sigmoid_approx(WEIGHTS_SCALE * sum[i]);
+    } else if (gate == 1) {
+      for (int i = 0; i < N; ++i) r[i] = sigmoid_approx(WEIGHTS_SCALE * sum[i]);
+    } else {
+      for (int i = 0; i < N; ++i) {
+        float t = WEIGHTS_SCALE * sum[i];
+        t = t < 0 ? 0 : t; /* ReLU */
+        h[i] = z[i] * state[i] + (1 - z[i]) * t;
+      }
+    }
   }
   memcpy(state, h, sizeof(float) * N);
 }
@@ -544,7 +654,7 @@ static void compute_rnn(const afo_rnn_weights *w, afo_rnn_state *st, float *gain
 }
 
 /* debug tap of the last processed frame (tests compare GPU intermediates against it) */
-afo_rnn_debug afo_rnn_last;
+__thread afo_rnn_debug afo_rnn_last; /* per thread: the all-cores baseline leg runs one stream per thread */
 
 /* --------------------------------------------------------- DenoiseState */
 void afo_rnn_state_init(afo_rnn_state *st) {

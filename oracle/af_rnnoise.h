@@ -41,7 +41,7 @@ typedef struct {
   int pitch_index, silence;
   float pitch_gain;
 } afo_rnn_debug;
-extern afo_rnn_debug afo_rnn_last;
+extern __thread afo_rnn_debug afo_rnn_last;
 
 void afo_rnn_weights_synthetic(afo_rnn_weights *w, uint64_t seed);
 void afo_rnn_state_init(afo_rnn_state *st);
@@ -63,6 +63,9 @@ void afo_rnnoise_benchmark_frames(const float *in, float *out, size_t n, uint64_
 
 /* evaluation order of the long sums: 0 = wavefront-native (the GPU's), 1 = published scalar C (see af_rnnoise.c) */
 extern int afo_rnn_eval_order;
+/* 0 = the checker's transforms; 1 = packed 480-point mixed-radix transforms for the timed CPU baseline (same results to the
+ * last bits; see af_rnnoise.c) */
+extern int afo_rnn_fft_mode;
 /* RNNoiseProcessor::scale_sample_for_model (rnnoise.rs:89-111) */
 float afo_scale_sample_for_model(float sample);
 
