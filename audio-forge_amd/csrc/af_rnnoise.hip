@@ -206,26 +206,51 @@ __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
 // twiddles between the two), applies W_960^(n2 k1), and the fifteen 64-point transforms across lanes run as
 // two passes of radix-8 butterflies through LDS (120 butterflies per pass, two per lane).
 // out[k] = sum_n in[n] exp(-2 pi i k n / 960) * scale.
+//
+// The three transform kernels (spectrum, pitch spectrum, resynthesis) run as workgroups of FOUR waves, each wave on
+// its own (stream, frames) unit with a private 8.6 KB transform buffer.  What the waves share, read-only after one
+// workgroup barrier, are the tables: the per-lane twiddles W_960^(lane k1) and W_64^(q r), the analysis window, the
+// band tables.  Kept per wave in registers (the first form of these kernels) the twiddles and the window cost 61
+// VGPRs, the kernels needed 180-232 and ran two waves per SIMD, latency bound (waves parked 50-74 % of their cycles);
+// with the tables in LDS they fit three waves per SIMD (measured on the spectrum kernel alone: 1.44 -> 0.94 ms per
+// 50-frame window).  A wave only ever synchronises with itself: LDS instructions of one wave execute in issue order,
+// so a wave-level fence (wait for its own LDS traffic, no compiler motion across) is all the "barrier" a private
+// buffer needs.
+__constant__ uint16_t c_blk_first[54] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224, 232, 240, 248, 256, 264, 272, 280, 288, 296, 304, 312, 320, 328, 336, 344, 352, 360, 368, 376, 384, 392};
+__constant__ uint8_t c_blk_count[54] = {4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
+__constant__ uint8_t c_seg_blk0[21] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21, 24, 28, 34, 43};
+__constant__ uint8_t c_seg_nblk[21] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 6, 9, 11};
+constexpr int kBandBlocks = 54;
 constexpr int kFftBuf = 15 * 72;  // fifteen 8 x 8 tiles with 9-element rows: conflict-free in both passes
+constexpr int kFftWaves = 4;      // waves (independent units) per transform workgroup
+#ifndef AF_FFT_PREFETCH
+#define AF_FFT_PREFETCH 1
+#endif
+constexpr int kBandSkewLen = 404 + (404 >> 3) + 1;  // a per-bin array laid out with one pad word every eight bins
+
+__device__ __forceinline__ int band_skew(int bin) { return bin + (bin >> 3); }
+
+struct FftShared {
+  float2 tw960[15 * 64];  // [k1][lane] = W_960^(lane k1)
+  float2 tw64[8 * 8];     // [r][q]     = W_64^(q r)
+  float win[kRnnFrame];   // half of the symmetric analysis / synthesis window
+  float frac[kBandSkewLen];  // position of a bin inside its band, at band_skew(bin)
+  int32_t band_of[484];
+  float dct6[kRnnBands * 6];  // the first six columns of the DCT matrix, [row][column]
+  uint16_t blk_first[64];
+  uint8_t blk_count[64], seg_blk0[32], seg_nblk[32];
+};
 
 __device__ __forceinline__ float2 cmul(float2 x, float2 w) { return make_float2(x.x * w.x - x.y * w.y, x.x * w.y + x.y * w.x); }
 __device__ __forceinline__ float2 cadd(float2 x, float2 y) { return make_float2(x.x + y.x, x.y + y.y); }
 __device__ __forceinline__ float2 csub(float2 x, float2 y) { return make_float2(x.x - y.x, x.y - y.y); }
 __device__ __forceinline__ float2 mulmj(float2 z) { return make_float2(z.y, -z.x); }  // z * (-i)
 
-// Per-lane twiddles are loop invariants of the whole kernel: W_960^(lane*k1) for the fifteen k1 and
-// W_64^(q r) of the lane's radix-8 cell live in registers.
-struct FftLane {
-  float2 tw960[15];
-  float2 tw64[8];
-};
-__device__ __forceinline__ FftLane fft_lane_init(const float2 *tw, int lane) {
-  FftLane f;
-#pragma unroll
-  for (int k1 = 0; k1 < 15; ++k1) f.tw960[k1] = tw[lane * k1];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) f.tw64[r] = tw[15 * (lane & 7) * r];
-  return f;
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in issue order; this keeps the compiler from moving them across and waits
+  // for the writes to land before other lanes of the same wave read them
+  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ void dft3(float2 x0, float2 x1, float2 x2, float2 &y0, float2 &y1, float2 &y2) {
@@ -271,14 +296,31 @@ __device__ __forceinline__ void dft8(const float2 *v, float2 *V) {
   V[7] = csub(b3, w3);
 }
 
-// In place: every pass reads its operands into registers, crosses a barrier, then writes over the same buffer
-// (which must hold kFftBuf elements) -- one 8.6 KB buffer per wave instead of two, i.e. half again as many
-// waves per CU for kernels whose occupancy is capped by LDS.  The result lands in a[0 .. 960).
-__device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int lane, float scale) {
+// the shared tables of a transform workgroup; the caller crosses one workgroup barrier afterwards
+__device__ __forceinline__ void fft_shared_init(FftShared &S, const SuppTables &tb, int tid, int nthreads) {
+  for (int i = tid; i < 15 * 64; i += nthreads) S.tw960[i] = tb.twiddle[(i & 63) * (i >> 6)];
+  for (int i = tid; i < 64; i += nthreads) S.tw64[i] = tb.twiddle[15 * (i & 7) * (i >> 3)];
+  for (int i = tid; i < kRnnFrame; i += nthreads) S.win[i] = tb.half_window[i];
+  for (int i = tid; i < 404; i += nthreads) S.frac[band_skew(i)] = tb.frac[i];
+  for (int i = tid; i < 484; i += nthreads) S.band_of[i] = tb.band_of_bin[i];
+  for (int i = tid; i < kRnnBands * 6; i += nthreads) S.dct6[i] = tb.dct[(i / 6) * kRnnBands + (i % 6)];
+  if (tid < 54) {
+    S.blk_first[tid] = c_blk_first[tid];
+    S.blk_count[tid] = c_blk_count[tid];
+  }
+  if (tid < 21) {
+    S.seg_blk0[tid] = c_seg_blk0[tid];
+    S.seg_nblk[tid] = c_seg_nblk[tid];
+  }
+}
+
+// In place: every pass reads its operands into registers, then writes over the same buffer (which must hold kFftBuf
+// elements and belongs to this wave alone).  The result lands in a[0 .. 960).
+__device__ __forceinline__ void fft960_wave(float2 *a, const FftShared &S, int lane, float scale) {
   float2 x[15];
 #pragma unroll
   for (int n1 = 0; n1 < 15; ++n1) x[n1] = a[64 * n1 + lane];
-  __syncthreads();
+  wave_lds_fence();
   {
     // n1 = (5 na + 3 nb) mod 15, k1 = (10 ka + 6 kb) mod 15: a plain 3 x 5 two-dimensional DFT
     float2 t[3][5];
@@ -292,36 +334,34 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int la
 #pragma unroll
       for (int kb = 0; kb < 5; ++kb) {
         const int k1 = (10 * ka + 6 * kb) % 15;
-        a[k1 * 72 + lane] = cmul(y[kb], fl.tw960[k1]);  // rows 72 apart: pass A's 8 x 8 reads of two rows hit disjoint banks
+        a[k1 * 72 + lane] = cmul(y[kb], S.tw960[k1 * 64 + lane]);  // rows 72 apart: pass A's 8 x 8 reads of two rows hit disjoint banks
       }
+      __builtin_amdgcn_sched_barrier(0);  // one group's twiddles at a time (fetched all at once they cost 30 registers)
     }
   }
-  __syncthreads();
+  wave_lds_fence();
   // 64 = 8 x 8, n2 = 8 p + q, k2 = r + 8 t.  Pass A: cell (k1, q): 8-point DFT over p, times W_64^(q r).
+  // A cell stays inside its row k1, and the lane's second cell sits eight rows further down: the two halves run one
+  // after the other (half the live registers of reading both first).
   {
-    float2 v0[8], v1[8];
-    const int id1 = lane + 64;
-    const int k1a = lane >> 3, q = lane & 7, k1b = id1 >> 3;
+    const int q = lane & 7;
 #pragma unroll
-    for (int pp = 0; pp < 8; ++pp) v0[pp] = a[k1a * 72 + 8 * pp + q];
-    if (id1 < 120) {
+    for (int half = 0; half < 2; ++half) {
+      const int id = lane + 64 * half, k1 = id >> 3;
+      if (id < 120) {
+        float2 v[8], V[8];
 #pragma unroll
-      for (int pp = 0; pp < 8; ++pp) v1[pp] = a[k1b * 72 + 8 * pp + q];
-    }
-    __syncthreads();
-    float2 V[8];
-    dft8(v0, V);
-    a[k1a * 72 + q] = V[0];
+        for (int pp = 0; pp < 8; ++pp) v[pp] = a[k1 * 72 + 8 * pp + q];
+        wave_lds_fence();
+        dft8(v, V);
+        a[k1 * 72 + q] = V[0];
 #pragma unroll
-    for (int r = 1; r < 8; ++r) a[k1a * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
-    if (id1 < 120) {
-      dft8(v1, V);
-      a[k1b * 72 + q] = V[0];
-#pragma unroll
-      for (int r = 1; r < 8; ++r) a[k1b * 72 + r * 9 + q] = cmul(V[r], fl.tw64[r]);
+        for (int r = 1; r < 8; ++r) a[k1 * 72 + r * 9 + q] = cmul(V[r], S.tw64[r * 8 + q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
+  wave_lds_fence();
   // Pass B: cell (k1, r): 8-point DFT over q; output bin k1 + 15 (r + 8 t).
   {
     float2 v0[8], v1[8];
@@ -333,7 +373,7 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int la
 #pragma unroll
       for (int q = 0; q < 8; ++q) v1[q] = a[k1b * 72 + r * 9 + q];
     }
-    __syncthreads();
+    wave_lds_fence();
     float2 V[8];
     dft8(v0, V);
 #pragma unroll
@@ -344,7 +384,7 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftLane &fl, int la
       for (int t = 0; t < 8; ++t) a[k1b + 15 * (r + 8 * t)] = make_float2(V[t].x * scale, V[t].y * scale);
     }
   }
-  __syncthreads();
+  wave_lds_fence();
 }
 
 // ---- evaluation orders shared with the CPU restatement (oracle/af_rnnoise.c, "pitch tools") ----------
@@ -370,96 +410,118 @@ __device__ __forceinline__ float wave_dot64_sq_stride2(const float *y, int n, in
 // falling ramp over band b's bins.  Evaluation order (shared with the CPU restatement): every band segment is
 // cut into blocks of 8 bins (54 blocks in all, one lane each), a block is summed left to right, and a
 // segment's block sums are added in block order -- a dependent chain of 8 + 11 additions instead of 88.
-// `frac` holds (float)j / (float)band_size per bin, evaluated once on the host (the same IEEE division).
-// `scratch` is 128 floats of LDS.  Lanes 0..21 return band `lane`.
-__constant__ uint16_t c_blk_first[54] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224, 232, 240, 248, 256, 264, 272, 280, 288, 296, 304, 312, 320, 328, 336, 344, 352, 360, 368, 376, 384, 392};
-__constant__ uint8_t c_blk_count[54] = {4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8};
-__constant__ uint8_t c_seg_blk0[21] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 21, 24, 28, 34, 43};
-__constant__ uint8_t c_seg_nblk[21] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 6, 9, 11};
-constexpr int kBandBlocks = 54;
-
-__device__ __forceinline__ float band_accumulate_wave(const float2 *X, const float2 *Pm, const float *frac, int lane,
-                                                      float *scratch) {
+// The caller leaves the per-bin products x.re p.re + x.im p.im of bins 0..399 in `prod` at band_skew(bin): a lane
+// that walks its block of eight consecutive bins then meets a different bank than its neighbours (stride 9), where
+// the plain layout made every one of these reads, and those of `frac`, an 8-way bank conflict.
+// `scratch` is 128 floats of this wave's LDS.  Lanes 0..21 return band `lane`.
+__device__ __forceinline__ float band_sums_wave(const float *prod, float *scratch, const FftShared &S, int lane) {
+  wave_lds_fence();  // the products are in place
   float rise = 0.0f, fall = 0.0f;
   if (lane < kBandBlocks) {
-    const int e0 = c_blk_first[lane], count = c_blk_count[lane];
+    const int e0 = S.blk_first[lane], count = S.blk_count[lane];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < count) {
-        const float2 x = X[e0 + j], p = Pm[e0 + j];
-        const float fr = frac[e0 + j];
-        const float tmp = x.x * p.x + x.y * p.y;
+        const int idx = band_skew(e0 + j);
+        const float tmp = prod[idx];
+        const float fr = S.frac[idx];
         fall += (1 - fr) * tmp;
         rise += fr * tmp;
       }
     }
   }
-  __syncthreads();  // earlier readers of scratch are done
   scratch[lane] = rise;
   scratch[64 + lane] = fall;
-  __syncthreads();
+  wave_lds_fence();
   float band = 0.0f;
   if (lane < kRnnBands) {
     float r = 0.0f, f = 0.0f;
     if (lane > 0) {
-      const int k0 = c_seg_blk0[lane - 1], nk = c_seg_nblk[lane - 1];
+      const int k0 = S.seg_blk0[lane - 1], nk = S.seg_nblk[lane - 1];
       for (int k = 0; k < nk; ++k) r += scratch[k0 + k];
     }
     if (lane < kRnnBands - 1) {
-      const int k0 = c_seg_blk0[lane], nk = c_seg_nblk[lane];
+      const int k0 = S.seg_blk0[lane], nk = S.seg_nblk[lane];
       for (int k = 0; k < nk; ++k) f += scratch[64 + k0 + k];
     }
     band = r + f;
     if (lane == 0 || lane == kRnnBands - 1) band *= 2;
   }
+  wave_lds_fence();  // the sums are read: `scratch` and `prod` may be written again
   return band;
 }
 
 // interp_band_gain value at one bin
-__device__ __forceinline__ float interp_gain(const float *bandE, const float *frac, const int32_t *band_of_bin, int bin) {
+__device__ __forceinline__ float interp_gain(const float *bandE, const FftShared &S, int bin) {
   if (bin >= (100 << 2)) return 0.0f;
-  const int b = band_of_bin[bin];
-  const float f = frac[bin];
+  const int b = S.band_of[bin];
+  const float f = S.frac[band_skew(bin)];
   return (1 - f) * bandE[b] + f * bandE[b + 1];
 }
 
-// ============================================================================== analysis, part 1
-// One wave per (frame, stream): window, forward transform, band energies.  Fully parallel.
-struct SpectrumLds {
+// wave-private LDS of a transform unit: the transform buffer; once the spectrum sits in its first 481 slots the rest
+// of it serves as the per-bin product array, the block-sum scratch and a few 22-entry band vectors
+struct FftUnitLds {
   float2 fa[kFftBuf];
-  float frac[404];
-  float bandtmp[128];
+  __device__ float *prod() { return reinterpret_cast<float *>(fa + kRnnFreq + 1); }
+  __device__ float *scratch() { return prod() + kBandSkewLen + 1; }
+  __device__ float *small() { return scratch() + 128; }  // 6 x 32 floats
 };
+static_assert((kRnnFreq + 1) * 2 + kBandSkewLen + 1 + 128 + 6 * 32 <= kFftBuf * 2, "the tail of the transform buffer holds the band work arrays");
 
-// Frames handled by one wave of the frame-parallel kernels: the per-wave setup (twiddles, tables) is
-// a dozen dependent global loads, comparable to one transform, so it is shared by kFramesPerWave frames.
+// ============================================================================== analysis, part 1
+// One wave per (stream, group of frames): window, forward transform, band energies.  Fully parallel.
+
+// Frames handled by one wave of the frame-parallel kernels: the per-wave setup is shared by kFramesPerWave frames.
 constexpr int kFramesPerWave = 10;  // measured with the butterfly transform: 1 -> 357 ms per bench step, 5 -> 338, 10 -> 336
 
-extern "C" __global__ __launch_bounds__(64, 2) void supp_spectrum_kernel(SuppArgs a, SuppTables tb) {
-  __shared__ SpectrumLds L;
-  const int lane = threadIdx.x;
+// a lane's 15 window coefficients sit at i = lane + 64 j of the symmetric 960-point window
+__device__ __forceinline__ float window_at(const FftShared &S, int i) { return S.win[i < kRnnFrame ? i : kRnnWindow - 1 - i]; }
+
+extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_spectrum_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ FftShared S;
+  __shared__ FftUnitLds U[kFftWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  fft_shared_init(S, tb, tid, 64 * kFftWaves);
+  __syncthreads();  // the only workgroup barrier: from here on every wave works on its own unit
   const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
-  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
+  const int64_t unit = (int64_t)blockIdx.x * kFftWaves + wave;
+  if (unit >= (int64_t)a.n_streams * groups) return;
+  const int s = (int)(unit / groups), fg = (int)(unit % groups);
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
-  const FftLane fl = fft_lane_init(tb.twiddle, lane);
-  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  float win[15];
-#pragma unroll
-  for (int j = 0; j < 15; ++j) {
-    const int i = lane + 64 * j;
-    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-  }
-  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
-    const int64_t cell = (int64_t)f * a.n_streams + s;
+  FftUnitLds &L = U[wave];
+  float nxt[15];  // the next frame's samples travel while this frame is transformed
+  auto fetch = [&](int f) {
     const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 15; ++j) L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow + lane + 64 * j] * win[j], 0.0f);
-    __syncthreads();
-    fft960_wave(L.fa, fl, lane, 1.0f / kRnnWindow);
+    for (int j = 0; j < 15; ++j) nxt[j] = pb[kPitchBuf - kRnnWindow + lane + 64 * j];
+  };
+  const int f_end = (fg + 1) * kFramesPerWave < a.n_frames ? (fg + 1) * kFramesPerWave : a.n_frames;
+  fetch(fg * kFramesPerWave);
+  for (int f = fg * kFramesPerWave; f < f_end; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+#pragma unroll
+    for (int j = 0; j < 15; ++j) L.fa[lane + 64 * j] = make_float2(nxt[j] * window_at(S, lane + 64 * j), 0.0f);
+#if AF_FFT_PREFETCH
+    if (f + 1 < f_end) fetch(f + 1);
+#endif
+    wave_lds_fence();
+    fft960_wave(L.fa, S, lane, 1.0f / kRnnWindow);
+#if !AF_FFT_PREFETCH
+    if (f + 1 < f_end) fetch(f + 1);
+#endif
     float2 *Xg = a.X + cell * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) Xg[i] = L.fa[i];
-    const float ex = band_accumulate_wave(L.fa, L.fa, L.frac, lane, L.bandtmp);
+    float *prod = L.prod();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < kRnnFreq) {
+        const float2 x = L.fa[i];
+        Xg[i] = x;
+        if (i < 400) prod[band_skew(i)] = x.x * x.x + x.y * x.y;
+      }
+    }
+    const float ex = band_sums_wave(prod, L.scratch(), S, lane);
     if (lane < kRnnBands) a.rec[cell].Ex[lane] = ex;
   }
 }
@@ -895,67 +957,98 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a
 }
 
 // ============================================================================== analysis, part 3
-// One wave per (frame, stream): pitch-aligned transform, band energy / correlation, their cepstral features.
-struct PitchSpecLds {
-  float2 fa[kFftBuf];
-  float2 X[kRnnFreq + 3];
-  float frac[404];
-  float Exp[kRnnBands];
-  float bandtmp[128];
-};
-
-extern "C" __global__ __launch_bounds__(64, 2) void supp_pitchspec_kernel(SuppArgs a, SuppTables tb) {
-  __shared__ PitchSpecLds L;
-  const int lane = threadIdx.x;
+// One wave per (stream, group of frames): pitch-aligned transform, band energy / correlation, their cepstral features.
+// The frame's spectrum X stays in registers (a lane owns bins lane + 64 j of X and of P alike).
+extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_pitchspec_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ FftShared S;
+  __shared__ FftUnitLds U[kFftWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  fft_shared_init(S, tb, tid, 64 * kFftWaves);
+  __syncthreads();
   const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
-  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
+  const int64_t unit = (int64_t)blockIdx.x * kFftWaves + wave;
+  if (unit >= (int64_t)a.n_streams * groups) return;
+  const int s = (int)(unit / groups), fg = (int)(unit % groups);
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
-  const FftLane fl = fft_lane_init(tb.twiddle, lane);
-  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  float win[15];
-#pragma unroll
-  for (int j = 0; j < 15; ++j) {
-    const int i = lane + 64 * j;
-    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
+  FftUnitLds &L = U[wave];
+  const int f_begin = fg * kFramesPerWave;
+  const int f_end = (fg + 1) * kFramesPerWave < a.n_frames ? (fg + 1) * kFramesPerWave : a.n_frames;
+  // the unit's pitch decisions come first: where the next frame's window starts depends on them
+  int my_pitch = 0, my_silence = 0;
+  if (f_begin + lane < f_end) {
+    const SuppFrameRec *r = a.rec + ((int64_t)(f_begin + lane) * a.n_streams + s);
+    my_pitch = r->pitch_index;
+    my_silence = r->silence;
   }
-  float dctcol[kRnnBands];
-#pragma unroll
-  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < 6 ? lane : 0)];
-  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
-    const int64_t cell = (int64_t)f * a.n_streams + s;
+  float nxt[15];
+  auto fetch = [&](int f) {
+    const int pitch_index = __builtin_amdgcn_readlane(my_pitch, f - f_begin);
     const float *pb = a.xh + (int64_t)s * (kPitchBuf + n) + (int64_t)(f + 1) * kRnnFrame;
-    SuppFrameRec *rec = a.rec + cell;
-    const int pitch_index = rec->pitch_index;
-    const bool silence = rec->silence != 0;
-    const float2 *Xg = a.X + cell * kRnnFreq;
-    __syncthreads();
-    for (int i = lane; i < kRnnFreq; i += 64) L.X[i] = Xg[i];
 #pragma unroll
-    for (int j = 0; j < 15; ++j)
-      L.fa[lane + 64 * j] = make_float2(pb[kPitchBuf - kRnnWindow - pitch_index + lane + 64 * j] * win[j], 0.0f);
-    __syncthreads();
-    fft960_wave(L.fa, fl, lane, 1.0f / kRnnWindow);
+    for (int j = 0; j < 15; ++j) nxt[j] = pb[kPitchBuf - kRnnWindow - pitch_index + lane + 64 * j];
+  };
+  fetch(f_begin);
+  for (int f = f_begin; f < f_end; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+    SuppFrameRec *rec = a.rec + cell;
+    const bool silence = __builtin_amdgcn_readlane(my_silence, f - f_begin) != 0;
+    const float2 *Xg = a.X + cell * kRnnFreq;
+    float2 Xr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      Xr[j] = i < kRnnFreq ? Xg[i] : make_float2(0.0f, 0.0f);
+    }
+    float ex = 0.0f;
+    if (lane < kRnnBands) ex = rec->Ex[lane];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) L.fa[lane + 64 * j] = make_float2(nxt[j] * window_at(S, lane + 64 * j), 0.0f);
+#if AF_FFT_PREFETCH
+    if (f + 1 < f_end) fetch(f + 1);
+#endif
+    wave_lds_fence();
+    fft960_wave(L.fa, S, lane, 1.0f / kRnnWindow);
+#if !AF_FFT_PREFETCH
+    if (f + 1 < f_end) fetch(f + 1);
+#endif
     float2 *Pg = a.P + cell * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) Pg[i] = L.fa[i];
-    const float ep = band_accumulate_wave(L.fa, L.fa, L.frac, lane, L.bandtmp);
-    float exp_ = band_accumulate_wave(L.X, L.fa, L.frac, lane, L.bandtmp);
+    float *prod = L.prod();
+    float2 Pr[7];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < kRnnFreq) {
+        const float2 p = L.fa[i];
+        Pg[i] = p;
+        if (j < 7) Pr[j] = p;
+        if (i < 400) prod[band_skew(i)] = p.x * p.x + p.y * p.y;
+      }
+    }
+    const float ep = band_sums_wave(prod, L.scratch(), S, lane);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int i = lane + 64 * j;
+      if (i < 400) prod[band_skew(i)] = Xr[j].x * Pr[j].x + Xr[j].y * Pr[j].y;
+    }
+    float exp_ = band_sums_wave(prod, L.scratch(), S, lane);
+    float *bandv = L.small();
     if (lane < kRnnBands) {
-      const float ex = rec->Ex[lane];
       exp_ = exp_ / sqrtf(.001f + ex * ep);
       rec->Ep[lane] = ep;
       rec->Exp[lane] = exp_;
-      L.Exp[lane] = exp_;
+      bandv[lane] = exp_;
     }
-    __syncthreads();
+    wave_lds_fence();
     if (!silence && lane < 6) {  // dct(tmp, Exp), first six coefficients
       float sum = 0;
 #pragma unroll
-      for (int j = 0; j < kRnnBands; ++j) sum += L.Exp[j] * dctcol[j];
+      for (int j = 0; j < kRnnBands; ++j) sum += bandv[j] * S.dct6[j * 6 + lane];
       float v = sum * sqrtf(2.0f / 22);
       if (lane == 0) v -= 1.3f;
       if (lane == 1) v -= 0.9f;
       rec->feat[kRnnBands + 12 + lane] = v;
     }
+    wave_lds_fence();
   }
 }
 
@@ -1004,12 +1097,6 @@ constexpr int kRnnBiasTiles = 37;  // dense 2 | vad z r h 2 each | noise z r h 3
 constexpr int kRnnTablePad = 208;
 constexpr int kW4Ahead = 3;        // weight groups in flight ahead of the one being consumed
 
-__device__ __forceinline__ void wave_lds_fence() {
-  // LDS operations of one wave execute in issue order; this keeps the compiler from moving them across and waits
-  // for the writes to land before other lanes of the same wave read them
-  __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // NC chains (tiles 0 .. NC - 1 of matrix MATRIX) through its K.  Weights come through a buffer descriptor over the
 // whole w4 blob: address = descriptor base + lane * 4 (the one VGPR) + a compile-time scalar offset, so no load needs
@@ -1359,96 +1446,107 @@ __global__ __launch_bounds__(64 * kWaves, 2) void supp_rnn_kernel(SuppArgs a, Rn
 }
 
 // ============================================================================== synthesis
-struct SynthLds {
-  float frac[404];
-  int32_t band_of[484];
-  float2 fa[kFftBuf];
-  float2 X[kRnnFreq + 3], P[kRnnFreq + 3];
-  float Ex[kRnnBands], Ep[kRnnBands], Exp[kRnnBands], g[kRnnBands], graw[kRnnBands], r[kRnnBands], norm[kRnnBands];
-  float bandtmp[128];
-};
-
-// One wave per (frame, stream): comb filter, gains, inverse transform, synthesis window.  The 960 windowed
+// One wave per (stream, group of frames): comb filter, gains, inverse transform, synthesis window.  The 960 windowed
 // samples of the frame overwrite the cell's P spectrum (no longer needed: 481 complex = 962 floats >= 960).
-extern "C" __global__ __launch_bounds__(64, 2) void supp_resynth_kernel(SuppArgs a, SuppTables tb) {
-  __shared__ SynthLds L;
-  const int lane = threadIdx.x;
+// X and P are elementwise work on a lane's own bins (lane + 64 j), so they live in registers; the transform buffer is
+// free until the inverse transform and lends its space to the band sums.
+extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_resynth_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ FftShared S;
+  __shared__ FftUnitLds U[kFftWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  fft_shared_init(S, tb, tid, 64 * kFftWaves);
+  __syncthreads();
   const int groups = (a.n_frames + kFramesPerWave - 1) / kFramesPerWave;
-  const int s = (int)(blockIdx.x / groups), fg = (int)(blockIdx.x % groups);
-  for (int i = lane; i < 404; i += 64) L.frac[i] = tb.frac[i];
-  for (int i = lane; i < 484; i += 64) L.band_of[i] = tb.band_of_bin[i];
-  const FftLane fl = fft_lane_init(tb.twiddle, lane);
-  float win[15];
-#pragma unroll
-  for (int j = 0; j < 15; ++j) {
-    const int i = lane + 64 * j;
-    win[j] = tb.half_window[i < kRnnFrame ? i : kRnnWindow - 1 - i];
-  }
-  for (int f = fg * kFramesPerWave; f < (fg + 1) * kFramesPerWave && f < a.n_frames; ++f) {
+  const int64_t unit = (int64_t)blockIdx.x * kFftWaves + wave;
+  if (unit >= (int64_t)a.n_streams * groups) return;
+  const int s = (int)(unit / groups), fg = (int)(unit % groups);
+  FftUnitLds &L = U[wave];
+  float *prod = L.prod();
+  float *rv = L.small(), *normv = rv + 32, *gv = rv + 64;  // band vectors the per-bin interpolation gathers from
+  const int f_end = (fg + 1) * kFramesPerWave < a.n_frames ? (fg + 1) * kFramesPerWave : a.n_frames;
+  for (int f = fg * kFramesPerWave; f < f_end; ++f) {
     const int64_t cell = (int64_t)f * a.n_streams + s;
-    __syncthreads();
     const SuppFrameRec *rec = a.rec + cell;
     const float2 *Xg = a.X + cell * kRnnFreq;
     float2 *Pg = a.P + cell * kRnnFreq;
-    for (int i = lane; i < kRnnFreq; i += 64) {
-      L.X[i] = Xg[i];
-      L.P[i] = Pg[i];
+    float2 Xr[8], Pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      Xr[j] = i < kRnnFreq ? Xg[i] : make_float2(0.0f, 0.0f);
+      Pr[j] = i < kRnnFreq ? Pg[i] : make_float2(0.0f, 0.0f);
     }
+    float Ex = 0.0f, Ep = 0.0f, Exp = 0.0f, g = 0.0f, graw = 0.0f;
     if (lane < kRnnBands) {
-      L.Ex[lane] = rec->Ex[lane];
-      L.Ep[lane] = rec->Ep[lane];
-      L.Exp[lane] = rec->Exp[lane];
-      L.g[lane] = rec->gains[lane];
-      L.graw[lane] = rec->gains_raw[lane];
+      Ex = rec->Ex[lane];
+      Ep = rec->Ep[lane];
+      Exp = rec->Exp[lane];
+      g = rec->gains[lane];
+      graw = rec->gains_raw[lane];
     }
     const bool silence = rec->silence != 0;
-    __syncthreads();
     if (!silence) {
       // ---- pitch_filter (denoise.c): comb-filter the bands the network trusts less than the pitch
       if (lane < kRnnBands) {
-        const float e = L.Exp[lane], g = L.graw[lane];
+        const float e = Exp;
         float r;
-        if (e > g) r = 1;
-        else r = e * e * (1 - g * g) / (.001f + g * g * (1 - e * e));
+        if (e > graw) r = 1;
+        else r = e * e * (1 - graw * graw) / (.001f + graw * graw * (1 - e * e));
         r = sqrtf(fminf(1.0f, fmaxf(0.0f, r)));
-        r *= sqrtf(L.Ex[lane] / (1e-8f + L.Ep[lane]));
-        L.r[lane] = r;
+        r *= sqrtf(Ex / (1e-8f + Ep));
+        rv[lane] = r;
+        gv[lane] = g;
       }
-      __syncthreads();
-      for (int i = lane; i < kRnnFreq; i += 64) {
-        const float rf = interp_gain(L.r, L.frac, L.band_of, i);
-        L.X[i].x += rf * L.P[i].x;
-        L.X[i].y += rf * L.P[i].y;
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < kRnnFreq) {
+          const float rf = interp_gain(rv, S, i);
+          Xr[j].x += rf * Pr[j].x;
+          Xr[j].y += rf * Pr[j].y;
+          if (i < 400) prod[band_skew(i)] = Xr[j].x * Xr[j].x + Xr[j].y * Xr[j].y;
+        }
       }
-      __syncthreads();
       {
-        const float newE = band_accumulate_wave(L.X, L.X, L.frac, lane, L.bandtmp);
-        if (lane < kRnnBands) L.norm[lane] = sqrtf(L.Ex[lane] / (1e-8f + newE));
+        const float newE = band_sums_wave(prod, L.scratch(), S, lane);
+        if (lane < kRnnBands) normv[lane] = sqrtf(Ex / (1e-8f + newE));
       }
-      __syncthreads();
-      for (int i = lane; i < kRnnFreq; i += 64) {
-        const float nf = interp_gain(L.norm, L.frac, L.band_of, i);
-        float2 v = L.X[i];
-        v.x *= nf;
-        v.y *= nf;
-        const float gf = interp_gain(L.g, L.frac, L.band_of, i);  // band gains after the lastg floor
-        v.x *= gf;
-        v.y *= gf;
-        L.X[i] = v;
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < kRnnFreq) {
+          const float nf = interp_gain(normv, S, i);
+          float2 v = Xr[j];
+          v.x *= nf;
+          v.y *= nf;
+          const float gf = interp_gain(gv, S, i);  // band gains after the lastg floor
+          v.x *= gf;
+          v.y *= gf;
+          Xr[j] = v;
+        }
       }
-      __syncthreads();
+      wave_lds_fence();  // every gather from the band vectors is done: the transform buffer may be filled
     }
     // ---- frame_synthesis: inverse transform through the forward FFT of the Hermitian extension
-    for (int i = lane; i < kRnnWindow; i += 64)
-      L.fa[i] = i < kRnnFreq ? L.X[i] : make_float2(L.X[kRnnWindow - i].x, -L.X[kRnnWindow - i].y);
-    __syncthreads();
-    fft960_wave(L.fa, fl, lane, 1.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < kRnnFreq) {
+        L.fa[i] = Xr[j];
+        if (i > 0 && i < kRnnFrame) L.fa[kRnnWindow - i] = make_float2(Xr[j].x, -Xr[j].y);
+      }
+    }
+    wave_lds_fence();
+    fft960_wave(L.fa, S, lane, 1.0f);
     float *y = reinterpret_cast<float *>(Pg);
 #pragma unroll
     for (int j = 0; j < 15; ++j) {
       const int i = lane + 64 * j;
-      y[i] = L.fa[(kRnnWindow - i) % kRnnWindow].x * win[j];
+      y[i] = L.fa[(kRnnWindow - i) % kRnnWindow].x * window_at(S, i);
     }
+    wave_lds_fence();
   }
 }
 
@@ -1504,8 +1602,9 @@ hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
 // workgroups per stream with a small footprint, and while its grid drains, kernels with larger workgroups (the network:
 // 256 VGPRs per wave) are not dispatched at all -- so the caller orders it after the previous window's network launch.
 hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream, hipEvent_t before_pitch) {
-  const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
-  hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
+  const int64_t units = (int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave);
+  const unsigned cells = (unsigned)((units + kFftWaves - 1) / kFftWaves);  // four units (waves) per transform workgroup
+  hipLaunchKernelGGL(supp_spectrum_kernel, dim3(cells), dim3(64 * kFftWaves), 0, stream, a, tb);
   if (before_pitch) {
     hipError_t err = hipStreamWaitEvent(stream, before_pitch, 0);
     if (err != hipSuccess) return err;
@@ -1521,8 +1620,9 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
 // pitch spectra and network launch can start while they run.
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
                                        hipEvent_t after_network, hipStream_t finish_stream) {
-  const unsigned cells = (unsigned)((int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave));
-  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64), 0, stream, a, tb);
+  const int64_t units = (int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave);
+  const unsigned cells = (unsigned)((units + kFftWaves - 1) / kFftWaves);  // four units (waves) per transform workgroup
+  hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64 * kFftWaves), 0, stream, a, tb);
   {
     // AF_RNN_VARIANT = waves (16 streams each) per workgroup: 1, 2 or 4.  Measured on one box, full bench step:
     // 4 -> 287-290 ms, 1 -> 298 ms (the round's first network kernel, a 4-wave workgroup per 16 streams: 301 ms)
@@ -1553,7 +1653,7 @@ hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, 
     if (err != hipSuccess) return err;
     fin = finish_stream;
   }
-  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64), 0, fin, a, tb);
+  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64 * kFftWaves), 0, fin, a, tb);
   hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, fin, a);
   return hipGetLastError();
 }
