@@ -23,11 +23,6 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
-bool tp_detect_supported(int control_block, int64_t n_samples);
-hipError_t launch_tp_detect(const float *audio, float *st32, BlockStats *stats, int64_t stream_stride, int64_t n_samples,
-                            int32_t n_streams, int32_t control_block, hipStream_t stream);
-hipError_t launch_chain_ring_part(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int part,
-                                  hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
                              hipStream_t stream);
 size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
@@ -80,8 +75,6 @@ struct af_engine {
   bool params_dirty = true;
   int kernel = AF_KERNEL_AUTO;
   int ring_variant = 0;
-  bool chain_split = false;  // two-launch form of the token-ring chain (measured slower: DESIGN.md 4.2c)
-  bool detector_kernel = false;  // output-side true-peak detector as its own kernel (measured slower: DESIGN.md 4.2d)
   bool timing = false;
   int64_t samples_processed = 0;
   int64_t last_blocks = 0;
@@ -100,16 +93,9 @@ struct af_engine {
   af::BlockStats *d_stats_pre = nullptr;   // rows of the pre-pass launch (auto-makeup)
   int64_t stats_pre_capacity = 0;
   af::ChainParams *d_params_pre = nullptr;
-  af::ChainParams uploaded_pre{};          // what d_params_pre holds (tracked by the split chain only)
-  bool uploaded_pre_valid = false;
-  double *d_side[2] = {nullptr, nullptr};  // split chain: gain-reduction targets of two windows in flight
-  int64_t side_capacity = 0;               // doubles per buffer
-  hipStream_t tail_stream = nullptr;       // split chain: the tail launches
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
   hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
-  hipStream_t post_stream = nullptr;       // the output-side true-peak detector of each finished chain window (af_truepeak.hip)
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> tail_ms_events;  // timing brackets of the tail launches of the last call
   af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
   af::ChainParams *d_params_de = nullptr;  // the de-esser pass reads the unedited parameter block
   af::ChainParams uploaded_de{};
@@ -328,12 +314,8 @@ void advance_crossfades(af_engine *e, int64_t n) {
 // `params_stream` is where parameter uploads are ordered; `stream` is where the kernels run.
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
-                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/,
-                         bool *detector_left_out = nullptr) {
-  // `detector_left_out`: the caller can run the output-side TruePeakDetector as a kernel of its own behind this launch
-  // (af_truepeak.hip); set to true when this launch left it out
+                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/) {
   af::ChainParams run = run_in;
-  if (detector_left_out) *detector_left_out = false;
   const int cb = run.control_block;
   const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
   bool any_xf = false;
@@ -427,7 +409,6 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
       AF_HIP(hipStreamSynchronize(stream));
       e->uploaded_valid = false;  // d_params now holds the post-pass variant
-      e->uploaded_pre_valid = false;
       AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
       af::LaunchArgs a1 = a;
       a1.params = e->d_params_pre;
@@ -451,10 +432,6 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       AF_HIP(af::launch_chain_ring(a2, post.n_eq_sections, post.lim.lookahead_samples, any_xf, e->ring_variant, auto_makeup, stream));
       e->last_launches += 2;
     } else {
-      if (detector_left_out && !deesser && layout == AF_LAYOUT_STREAM_MAJOR && af::tp_detect_supported(cb, n_samples)) {
-        run.flags |= af::kFlagNoOutDetector;
-        *detector_left_out = true;
-      }
       if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
         e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
         AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
@@ -486,102 +463,6 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   if (e->timing) {
     AF_HIP(hipEventRecord(t1, stream));
     e->chain_ms_events.push_back({t0, t1});
-  }
-  advance_crossfades(e, n_samples);
-  return AF_OK;
-}
-
-// The chain of one window as two launches on two streams (af_ring_kernel.hip, kMode 1 / 2): the head of window w+1
-// overlaps the tail of window w on other CUs.  Available for the plain compressor path of the token-ring kernel.
-bool chain_split_eligible(const af_engine *e, const af::ChainParams &run) {
-  static const int env_choice = [] {  // AF_CHAIN_SPLIT=0/1 overrides the engine's setting (A/B runs)
-    const char *env = std::getenv("AF_CHAIN_SPLIT");
-    return env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
-  }();
-  if (!(env_choice >= 0 ? env_choice != 0 : e->chain_split)) return false;
-  if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED) return false;
-  if (e->ring_variant != 0 && e->ring_variant != 1604) return false;
-  if (!(run.flags & af::kFlagCompressor) || run.comp.auto_makeup_enabled || (run.flags & af::kFlagDeesser)) return false;
-  if (run.control_block % 4 != 0) return false;
-  // decided once per call: sized for the crossfade layout so that every window of the call takes the same route
-  return af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, true) <= af::kMaxLdsBytes;
-}
-
-int launch_chain_split(af_engine *e, const af::ChainParams &run, const float *in, float *out, int64_t n_samples,
-                       int64_t stream_stride, int32_t layout, int64_t samples_before, af::BlockStats *stats,
-                       int64_t window_index, hipStream_t head_stream, hipStream_t tail_stream, hipEvent_t head_done,
-                       hipEvent_t tail_done, hipEvent_t side_free) {
-  const int cb = run.control_block;
-  const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
-  bool any_xf = false;
-  for (int k = 0; k < run.n_eq_sections; ++k) any_xf |= run.eq[k].xf_remaining > 0;
-  e->last_kernel_used = AF_KERNEL_PHASED;
-  const int64_t side_need = n_samples * e->n_streams;
-  if (side_need > e->side_capacity) {
-    AF_HIP(hipDeviceSynchronize());
-    for (double *&p : e->d_side) {
-      if (p) AF_HIP(hipFree(p));
-      p = nullptr;
-      AF_HIP(hipMalloc(&p, sizeof(double) * side_need));
-    }
-    e->side_capacity = side_need;
-  }
-  const uint32_t front_flags = af::kFlagInputScrub | af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
-  af::ChainParams head = run, tail = run;
-  head.flags = (head.flags & ~af::kFlagLimiter) | af::kFlagSplitHead;
-  tail.flags = (tail.flags & ~(af::kFlagEq | front_flags)) | af::kFlagSplitTail;
-  if (!e->uploaded_pre_valid || std::memcmp(&e->uploaded_pre, &head, sizeof head) != 0) {
-    e->uploaded_pre = head;  // engine-owned copy: stays valid until the async copy has run
-    AF_HIP(hipMemcpyAsync(e->d_params_pre, &e->uploaded_pre, sizeof head, hipMemcpyHostToDevice, head_stream));
-    AF_HIP(hipStreamSynchronize(head_stream));  // rare: first launch, and while EQ crossfades advance
-    e->uploaded_pre_valid = true;
-  }
-  if (!e->uploaded_valid || std::memcmp(&e->uploaded, &tail, sizeof tail) != 0) {
-    e->uploaded = tail;
-    AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof tail, hipMemcpyHostToDevice, tail_stream));
-    AF_HIP(hipStreamSynchronize(tail_stream));
-    e->uploaded_valid = true;
-  }
-  af::LaunchArgs a{};
-  a.st64 = e->d_st64;
-  a.st32 = e->d_st32;
-  a.in = in;
-  a.out = out;
-  a.stats = stats;
-  a.status = e->d_status;
-  a.params = e->d_params_pre;
-  a.n_samples = n_samples;
-  a.stream_stride = stream_stride;
-  a.samples_before = samples_before;
-  a.n_streams = e->n_streams;
-  a.layout = layout;
-  a.side = e->d_side[window_index & 1];
-  a.side_stride = n_samples;
-  hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr, t3 = nullptr;
-  if (e->timing) {
-    AF_HIP(hipEventCreate(&t0));
-    AF_HIP(hipEventCreate(&t1));
-    AF_HIP(hipEventCreate(&t2));
-    AF_HIP(hipEventCreate(&t3));
-  }
-  // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
-  AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, head_stream));
-  if (side_free) AF_HIP(hipStreamWaitEvent(head_stream, side_free, 0));  // the tail two windows back has read this buffer
-  if (t0) AF_HIP(hipEventRecord(t0, head_stream));
-  AF_HIP(af::launch_chain_ring_part(a, head.n_eq_sections, head.lim.lookahead_samples, any_xf, 1, head_stream));
-  if (t1) AF_HIP(hipEventRecord(t1, head_stream));
-  AF_HIP(hipEventRecord(head_done, head_stream));
-  AF_HIP(hipStreamWaitEvent(tail_stream, head_done, 0));
-  a.params = e->d_params;
-  a.in = out;
-  if (t2) AF_HIP(hipEventRecord(t2, tail_stream));
-  AF_HIP(af::launch_chain_ring_part(a, tail.n_eq_sections, tail.lim.lookahead_samples, any_xf, 2, tail_stream));
-  if (t3) AF_HIP(hipEventRecord(t3, tail_stream));
-  AF_HIP(hipEventRecord(tail_done, tail_stream));
-  e->last_launches += 2;
-  if (e->timing) {
-    e->chain_ms_events.push_back({t0, t1});
-    e->tail_ms_events.push_back({t2, t3});
   }
   advance_crossfades(e, n_samples);
   return AF_OK;
@@ -637,14 +518,9 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = e->fin_stream = nullptr;
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = nullptr;
   if (e->fin_stream) (void)hipStreamDestroy(e->fin_stream);
-  if (e->post_stream) (void)hipStreamDestroy(e->post_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
-  if (e->tail_stream) (void)hipStreamDestroy(e->tail_stream);
-  for (double *p : e->d_side)
-    if (p) (void)hipFree(p);
-  for (auto &pr : e->tail_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
   if (e->ana_stream) (void)hipStreamDestroy(e->ana_stream);
@@ -835,16 +711,6 @@ int af_engine_set_ring_variant(af_engine *e, int32_t waves, int32_t chunk) {
   e->ring_variant = v;
   return AF_OK;
 }
-int af_engine_set_chain_split(af_engine *e, int32_t on) {
-  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  e->chain_split = on != 0;
-  return AF_OK;
-}
-int af_engine_set_detector_kernel(af_engine *e, int32_t on) {
-  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  e->detector_kernel = on != 0;
-  return AF_OK;
-}
 int af_engine_last_kernel(const af_engine *e) { return e ? e->last_kernel_used : 0; }
 int af_engine_set_timing_enabled(af_engine *e, int32_t on) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
@@ -941,8 +807,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   e->chain_ms_events.clear();
-  for (auto &pr : e->tail_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  e->tail_ms_events.clear();
 
   if (!e->supp.enabled) {
     int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
@@ -1031,10 +895,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->trace_frames = frames;
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = e->tail_stream = e->post_stream = e->fin_stream = stream;
+    e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = stream;
     e->borrowed_streams = true;
   }
-  const bool split = chain_split_eligible(e, run);
 
   if (!e->aux_stream) {
     // CU partition.  A 16-wave chain workgroup needs a whole CU (it fills the register file), and the suppressor's
@@ -1059,11 +922,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->post_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->post_stream, &e->fin_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -1075,31 +937,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
-  if (!e->post_stream) AF_HIP(hipStreamCreateWithFlags(&e->post_stream, hipStreamNonBlocking));
   if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
   static const bool split_synthesis = [] {  // AF_SYNTH_SPLIT=0: resynthesis + overlap-add stay behind the network on one stream
     const char *env = std::getenv("AF_SYNTH_SPLIT");
     return !env || std::atoi(env) != 0;
   }();
   const hipStream_t fin = split_synthesis ? e->fin_stream : nullptr;
-  static const int detector_env = [] {  // AF_TP_DETECT_KERNEL=0/1 overrides the engine's setting (A/B runs)
-    const char *env = std::getenv("AF_TP_DETECT_KERNEL");
-    return env ? (std::atoi(env) != 0 ? 1 : 0) : -1;
-  }();
-  const bool separate_detector = detector_env >= 0 ? detector_env != 0 : e->detector_kernel;
-  bool post_used = false;
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
-  if (split && !e->tail_stream) {
-    if (e->partition_chain_cus > 0) {  // the tail shares the chain's CUs (reserve twice the workgroup count for a split chain)
-      hipDeviceProp_t prop;
-      AF_HIP(hipGetDeviceProperties(&prop, e->device));
-      std::vector<uint32_t> chain_mask(prop.multiProcessorCount / 32, 0u);
-      for (int bit = 0; bit < e->partition_chain_cus; ++bit) chain_mask[bit >> 5] |= 1u << (bit & 31);
-      AF_HIP(hipExtStreamCreateWithCUMask(&e->tail_stream, (uint32_t)chain_mask.size(), chain_mask.data()));
-    } else {
-      AF_HIP(hipStreamCreateWithFlags(&e->tail_stream, hipStreamNonBlocking));
-    }
-  }
   int64_t blocks_done = 0;
   size_t ev_index = 0;
   auto next_event = [&](hipEvent_t *out_ev) -> int {
@@ -1118,9 +962,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
     AF_HIP(hipStreamWaitEvent(e->pre_stream, ev, 0));
     AF_HIP(hipStreamWaitEvent(e->ana_stream, ev, 0));
-    if (split) AF_HIP(hipStreamWaitEvent(e->tail_stream, ev, 0));
     if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
-    if (e->post_stream != stream) AF_HIP(hipStreamWaitEvent(e->post_stream, ev, 0));
     if (fin && fin != stream) AF_HIP(hipStreamWaitEvent(fin, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
@@ -1158,17 +1000,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     return sa;
   };
   const int64_t n_windows = (int64_t)win_f0.size();
-  std::vector<hipEvent_t> pre_done(n_windows), ana_done(n_windows), syn_done(n_windows), head_done(n_windows), tail_done(n_windows);
+  std::vector<hipEvent_t> pre_done(n_windows), ana_done(n_windows), syn_done(n_windows);
   std::vector<hipEvent_t> rnn_done(n_windows);
   for (int64_t w = 0; w < n_windows; ++w) {
     if (int rc = next_event(&rnn_done[w])) return rc;
     if (int rc = next_event(&pre_done[w])) return rc;
     if (int rc = next_event(&ana_done[w])) return rc;
     if (int rc = next_event(&syn_done[w])) return rc;
-    if (split) {
-      if (int rc = next_event(&head_done[w])) return rc;
-      if (int rc = next_event(&tail_done[w])) return rc;
-    }
   }
   // Stages are enqueued in pipeline order (the pre-pass two windows and the analysis one window ahead of the
   // synthesis), so that every event a stage waits on has been recorded before the wait is enqueued.
@@ -1217,29 +1055,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
     static const bool diag_skip_chain = std::getenv("AF_DIAG_SKIP_CHAIN") != nullptr;  // timing experiments only
     int rc = AF_OK;
-    if (diag_skip_chain) {
-    } else if (split) {
-      // head of window w on the chain stream, tail on its own stream: tail(w) overlaps head(w+1) on other CUs
-      rc = launch_chain_split(e, run, out + seg0, out + seg0, seg_n, stream_stride, layout, e->samples_processed + seg0,
-                              e->d_stats + blocks_done * e->n_streams, w, e->aux_stream, e->tail_stream, head_done[w],
-                              tail_done[w], w >= 2 ? tail_done[w - 2] : nullptr);
-    } else {
-      bool left_out = false;
+    if (!diag_skip_chain)
       rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
-                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream,
-                                separate_detector ? &left_out : nullptr);
-      if (rc) return rc;
-      if (left_out) {  // the window's output-side true-peak detector, behind its chain launch, on the suppressor's CUs
-        hipEvent_t chain_done;
-        if (int rc2 = next_event(&chain_done)) return rc2;
-        AF_HIP(hipEventRecord(chain_done, e->aux_stream));
-        AF_HIP(hipStreamWaitEvent(e->post_stream, chain_done, 0));
-        AF_HIP(af::launch_tp_detect(out + seg0, e->d_st32, e->d_stats + blocks_done * e->n_streams, stream_stride, seg_n,
-                                    e->n_streams, cb, e->post_stream));
-        e->last_launches += 2;
-        post_used = true;
-      }
-    }
+                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream);
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
@@ -1252,18 +1070,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
-    if (split) {
-      hipEvent_t ev2;
-      if (int rc = next_event(&ev2)) return rc;
-      AF_HIP(hipEventRecord(ev2, e->tail_stream));
-      AF_HIP(hipStreamWaitEvent(stream, ev2, 0));
-    }
-    if (post_used && e->post_stream != stream) {
-      hipEvent_t ev3;
-      if (int rc = next_event(&ev3)) return rc;
-      AF_HIP(hipEventRecord(ev3, e->post_stream));
-      AF_HIP(hipStreamWaitEvent(stream, ev3, 0));
-    }
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
@@ -1408,11 +1214,6 @@ int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_m
     AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
     chain += (double)t;
   }
-  for (auto &pr : e->tail_ms_events) {
-    AF_HIP(hipEventSynchronize(pr.second));
-    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
-    chain += (double)t;
-  }
   *chain_ms = chain;  // summed over the chain launches of the call (they may overlap suppressor kernels)
   return AF_OK;
 }
@@ -1428,11 +1229,6 @@ int af_engine_last_chain_launch_ms(af_engine *e, double *first_ms, double *tail_
     AF_HIP(hipEventSynchronize(pr.second));
     AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
     *first_ms += (double)t;
-  }
-  for (auto &pr : e->tail_ms_events) {
-    AF_HIP(hipEventSynchronize(pr.second));
-    AF_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
-    *tail_ms += (double)t;
   }
   return AF_OK;
 }

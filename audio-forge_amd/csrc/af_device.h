@@ -97,9 +97,6 @@ enum ChainFlags : uint32_t {
   kFlagDcBlock = 1u << 7,      // routing.rs:826-843
   kFlagPreHighpass = 1u << 8,
   kFlagPrePass = 1u << 9,      // first of two launches: front end + EQ only, no detector, no compressor bookkeeping
-  kFlagSplitHead = 1u << 10,   // split chain, first launch: up to the compressor's static gain-reduction target
-  kFlagSplitTail = 1u << 11,   // split chain, second launch: from the gain-reduction smoothing on
-  kFlagNoOutDetector = 1u << 12,  // the output-side TruePeakDetector runs as a kernel of its own (af_truepeak.hip)
 };
 
 struct ChainParams {
@@ -169,8 +166,6 @@ struct LaunchArgs {
   int32_t *status;            // device word: non-zero when a kernel gave up on a token (never expected)
   const BlockStats *pre_stats;  // rows of the pre-pass launch (compressor-input block power), or null
   const double *vad_prob;     // [blocks][n_streams] speech posteriors for auto-makeup, or null
-  double *side;               // split chain: static gain-reduction targets [stream][side_stride], head -> tail
-  int64_t side_stride;
   int64_t n_samples;
   int64_t stream_stride;
   int64_t samples_before;     // samples processed by earlier launches (van-Herk phase)

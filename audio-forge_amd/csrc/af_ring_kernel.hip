@@ -132,17 +132,10 @@ __device__ __forceinline__ float tp_observe_ring(const float *ring, int n, int l
 }
 
 // kAuto: the compressor's auto-makeup controller and its loudness meter are compiled in.
-// kMode: 0 = the whole chain in one launch.  1 / 2 = the chain cut in two launches that run on different CUs, a window
-// apart (the chain is issue bound, and a 16-wave workgroup fills a CU's register file, so 4096 streams = 64 workgroups
-// can only ever use 64 CUs per launch):
-//   1 "head": front end, EQ, and the compressor's detector side up to the static gain-reduction target; leaves the
-//             compressor's input in `out` (f32) and the target in `side` (f64, the value the next token consumes);
-//   2 "tail": gain-reduction smoothing, gain, limiter, true-peak limiter / detector, output statistics.
-// Each launch owns (stages and writes back) only the state rows of its own tokens, so head(w+1) and tail(w) may overlap.
-template <int kRingWaves, int kChunk, bool kAuto, int kMode = 0>
+// (Round 1 also built this kernel cut in two launches at the compressor's static gain-reduction target, head and tail on
+// different CUs a window apart: bit-identical, but each half stayed as long as the whole -- DESIGN.md 4.2c; removed.)
+template <int kRingWaves, int kChunk, bool kAuto>
 __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchArgs a, const ChainParams *__restrict__ params) {
-  constexpr bool kHead = kMode == 1, kTail = kMode == 2;
-  static_assert(!(kAuto && kMode != 0), "auto-makeup has its own two-launch form");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   // The parameter block is a kernel argument of its own, `const __restrict__`: nothing this kernel stores can alias it, so
   // its fields are uniform scalar loads (through the scalar cache).  As a pointer inside LaunchArgs every field read was a
@@ -163,7 +156,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 #define L64(row) l64[(row)*kLanes + lane]
 #define L32(row) l32[(row)*kLanes + lane]
 
-  const bool out_detector = !(flags & (kFlagPrePass | kFlagNoOutDetector));  // this launch runs the output-side detector
+  const bool out_detector = !(flags & kFlagPrePass);  // this launch runs the output-side detector
   const int tid = threadIdx.x;
   const int lane = tid & (kLanes - 1);
   const int wave = tid / kLanes;
@@ -230,13 +223,12 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       L32(kR32NonFinite) = 0.0f;
     }
     // history rows: state row r holds sample n0-32+r
-    if constexpr (!kHead)
-      for (int r = wave; r < kTpTaps; r += kRingWaves) {
-        const int row = (int)((n0 - kTpTaps + r) & (kTpRing - 1));
-        L32(kR32Tpi + row) = a.st32[(int64_t)(kTpInHist + r) * NS + sc];
-        L32(kR32Tpo + row) = out_detector ? a.st32[(int64_t)(kTpOutHist + r) * NS + sc] : 0.0f;
-      }
-    if (!kHead && (flags & kFlagLimiter))
+    for (int r = wave; r < kTpTaps; r += kRingWaves) {
+      const int row = (int)((n0 - kTpTaps + r) & (kTpRing - 1));
+      L32(kR32Tpi + row) = a.st32[(int64_t)(kTpInHist + r) * NS + sc];
+      L32(kR32Tpo + row) = out_detector ? a.st32[(int64_t)(kTpOutHist + r) * NS + sc] : 0.0f;
+    }
+    if (flags & kFlagLimiter)
       for (int r = wave; r < 2 * W; r += kRingWaves) L32(kR32LimRing + r) = a.st32[(int64_t)(kLimRing + r) * NS + sc];
   }
   __syncthreads();
@@ -288,14 +280,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       }
 
       double target[kChunk];
-      if constexpr (kTail) {  // the head launch's static gain-reduction targets for this chunk
-        const double *sp = &a.side[(int64_t)s * a.side_stride + t0];
-  #pragma unroll
-        for (int k = 0; k < kChunk; ++k) target[k] = (valid && (kFull || k < len)) ? sp[k] : 0.0;
-      }
 
       // =========================== token: input scrub, block input stats, DC block + fixed HP
-      if constexpr (!kTail) {
       token_wait(turn, kTokIn, q);
       {
         double in_sq = first_in_block ? 0.0 : L64(kR64InSq);
@@ -344,10 +330,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
       }
       token_pass(turn, kTokIn, q);
-      }
 
       // =========================== tokens: EQ section groups (eq.rs:371-379, biquad.rs:263-327)
-      for (int g = 0; g < (kTail ? 0 : n_groups); ++g) {
+      for (int g = 0; g < n_groups; ++g) {
         const int k0 = g * kEqGroup;
         const int k1 = (k0 + kEqGroup) < nsec ? (k0 + kEqGroup) : nsec;
         token_wait(turn, kTokEq0 + g, q);
@@ -406,7 +391,6 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       // =========================== compressor (compressor.rs:700-774)
       if (flags & kFlagCompressor) {
         const CompressorParams &cp = P.comp;
-        if constexpr (!kTail) {
         double d[kChunk], inst_peak_db[kChunk], rms_db[kChunk], weight_db[kChunk];
         double low_e[kChunk], voiced_e[kChunk], presence_e[kChunk], rms_e[kChunk];
         // ---- token A: side-chain high-pass + band / rms envelopes (linear recurrences)
@@ -534,34 +518,6 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
             const double blended = 0.6 * db2lin(peak_db[k]) + 0.4 * db2lin(rms_db[k]);
             target[k] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_db[k]);
           }
-        }  // !kTail
-        if constexpr (kHead) {
-          // hand the chunk to the tail launch: compressor input in `out`, targets in `side`
-          if (valid) {
-            double *sp = &a.side[(int64_t)s * a.side_stride + t0];
-  #pragma unroll
-            for (int k = 0; k < kChunk; ++k)
-              if (kFull || k < len) sp[k] = target[k];
-            if (vec_ok && kFull) {
-              float *dst = &a.out[(int64_t)s * a.stream_stride + t0];
-              if constexpr (kChunk == 2) {
-                *reinterpret_cast<float2 *>(dst) = make_float2(x[0], x[1]);
-              } else {
-  #pragma unroll
-                for (int k4 = 0; k4 < kChunk; k4 += 4)
-                  *reinterpret_cast<float4 *>(dst + k4) = make_float4(x[k4], x[k4 + 1], x[k4 + 2], x[k4 + 3]);
-              }
-            } else {
-  #pragma unroll
-              for (int k = 0; k < kChunk; ++k)
-                if (kFull || k < len) {
-                  if (a.layout == 0) a.out[(int64_t)s * a.stream_stride + t0 + k] = x[k];
-                  else a.out[(t0 + k) * a.stream_stride + s] = x[k];
-                }
-            }
-          }
-          return;
-        }
         // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
         double gr_k[kChunk];
         double makeup_lin;
@@ -953,7 +909,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
                           {kR64ActScore, kCompActivityScore}, {kR64ActReliab, kCompActivityReliability},
                           {kR64CurrentLufs, kCompCurrentLufs}};
     constexpr int n_head64 = (int)(sizeof(head64) / sizeof(head64[0])), n_tail64 = (int)(sizeof(tail64) / sizeof(tail64[0]));
-    if constexpr (!kTail) {  // rows of the tokens up to the gain-reduction target
+    {  // rows of the tokens up to the gain-reduction target
       for (int k = wave; k < n_head64; k += kRingWaves) a.st64[(int64_t)head64[k].field * NS + s] = L64(head64[k].row);
       for (int k = wave; k < (any_xf ? 4 : 2) * nsec; k += kRingWaves) {
         const int sec = k >> (any_xf ? 2 : 1), part = k & (any_xf ? 3 : 1);
@@ -967,7 +923,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         a.st64[(int64_t)kPreZ2 * NS + s] = L64(kR64PreZ2);
       }
     }
-    if constexpr (!kHead) {  // rows of the tokens from the gain-reduction smoothing on
+    {  // rows of the tokens from the gain-reduction smoothing on
       for (int k = wave; k < n_tail64; k += kRingWaves) a.st64[(int64_t)tail64[k].field * NS + s] = L64(tail64[k].row);
       if (wave == 1 % kRingWaves && kAuto && P.comp.meter_slots > 0) {
         const int mbase = kF64Fixed + 4 * P.n_eq_sections;
@@ -1007,26 +963,19 @@ constexpr int kRingMaxDynamicLds = 160 * 1024 - 4096;  // the profile's static a
 #else
 constexpr int kRingMaxDynamicLds = 160 * 1024;
 #endif
-template <int kRingWaves, int kChunk, bool kAuto = false, int kMode = 0>
+template <int kRingWaves, int kChunk, bool kAuto = false>
 static hipError_t launch_variant(const LaunchArgs &args, size_t dyn, hipStream_t stream) {
   const int groups = (args.n_streams + kLanes - 1) / kLanes;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto, kMode>),
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(chain_ring_kernel<kRingWaves, kChunk, kAuto>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kRingMaxDynamicLds);
     if (err != hipSuccess) return err;
     attr_set = true;
   }
-  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk, kAuto, kMode>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream,
+  hipLaunchKernelGGL((chain_ring_kernel<kRingWaves, kChunk, kAuto>), dim3(groups), dim3(kRingWaves * kLanes), dyn, stream,
                      args, args.params);
   return hipGetLastError();
-}
-
-// The two launches of the split chain (kMode 1 / 2 above); `part` = 1 head, 2 tail.
-hipError_t launch_chain_ring_part(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int part,
-                                  hipStream_t stream) {
-  const size_t dyn = ring_lds_bytes(n_sections, lookahead_samples, crossfade);
-  return part == 1 ? launch_variant<16, 4, false, 1>(args, dyn, stream) : launch_variant<16, 4, false, 2>(args, dyn, stream);
 }
 
 // `variant` = waves * 100 + chunk; 0 picks the default

@@ -162,8 +162,6 @@ SIGNATURES = {
     "af_engine_set_timing_enabled": (C.c_int, [_vp, _i32]),
     "af_engine_last_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(_i32)]),
     "af_engine_last_stage_ms": (C.c_int, [_vp, _dp, _dp]),
-    "af_engine_set_chain_split": (C.c_int, [_vp, _i32]),
-    "af_engine_set_detector_kernel": (C.c_int, [_vp, _i32]),
     "af_engine_last_chain_launch_ms": (C.c_int, [_vp, _dp, _dp, C.POINTER(_i32)]),
     # product resampler
     "af_engine_last_kernel": (C.c_int, [_vp]),

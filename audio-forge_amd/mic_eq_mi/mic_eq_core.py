@@ -165,7 +165,7 @@ class Engine:
         return ms.value, launches.value
 
     def last_chain_launch_ms(self) -> tuple[float, float, int]:
-        """(summed ms of the whole-chain or split-head launches, summed ms of the split-tail launches, segments)."""
+        """(summed ms of the chain launches of the last call, 0.0, number of launches)."""
         first, tail, segments = C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
         _lib.check(self._lib.af_engine_last_chain_launch_ms(self._h, C.byref(first), C.byref(tail), C.byref(segments)))
         return first.value, tail.value, segments.value

@@ -77,52 +77,112 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
     return out
 
 
-def pmc_traffic(kernel_name: str, streams: int, samples_per_launch: float):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected separately, gfx950 correction applied; profiles/README.md).  The passes were taken with uniform
-    windows (AF_SUPP_RAMP=0: every chain launch covers `samples_per_launch` of the profile's launch shape); the chain's
-    traffic is proportional to the samples a launch covers, so the figure is scaled to this run's average launch.
-    None when the profile was taken at another batch size (counters cannot be read from inside this script)."""
-    path = ROOT / "profiles" / "r01_pmc_traffic.json"
+CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: max shader clock (the issue roof below is priced at it)
+
+
+def profile_counters(full: bool, streams: int, seconds: float):
+    """Counter figures of this workload from the committed rocprofv3 --pmc passes (profiles/r02_step_counters.json, written
+    by tools/step_counters.py from separate counter runs of this same command; counters cannot be read from inside a
+    timed run).  Returned only when the profile was taken at this shape; it carries the commit it was taken at."""
+    path = ROOT / "profiles" / "r02_step_counters.json"
     try:
         prof = json.loads(path.read_text())
     except (OSError, ValueError):
         return None
-    shape = prof.get("launch_shape", {})
-    if shape.get("streams") != streams or not shape.get("samples_per_launch"):
+    shape = prof.get("shape", {})
+    if shape.get("streams") != streams or shape.get("seconds") != seconds or shape.get("chain") != ("full" if full else "dynamics"):
         return None
-    base = kernel_name.split("<")[0]
-    for name, row in prof.get("kernels", {}).items():
-        if base in name and row.get("traffic_bytes_per_launch"):
-            return float(row["traffic_bytes_per_launch"]) * samples_per_launch / float(shape["samples_per_launch"])
-    return None
+    return prof
 
 
-def cpu_baseline(seconds: float, full: bool, budget_s: float = 15.0) -> dict:
-    """The oracle (CPU restatement of rust-core; the Rust reference cannot be built here) on 1 host thread."""
+def _percentile(values, q: float) -> float:
+    v = np.sort(np.asarray(values, dtype=np.float64))
+    pos = (v.size - 1) * q
+    lo, hi = int(np.floor(pos)), int(np.ceil(pos))
+    return float(v[lo] + (pos - lo) * (v[hi] - v[lo]))
+
+
+def cpu_baseline(seconds: float, full: bool) -> dict:
+    """The CPU restatement of rust-core (oracle/, KAT-pinned; the Rust reference cannot be built offline) timed on this
+    host, per SURVEY.md 8(d):
+      single_thread: one S1 stream x `seconds`, 1 warm-up + 7 repetitions, median and p95
+                     (python/tools/evaluate_limiter_lookahead.py:28,288-289,319-323);
+      all_cores:     S3 batch of 256 streams x 2 s, one stream shard per host thread (ctypes releases the GIL),
+                     1 warm-up + 3 repetitions, median;
+      suppressor:    per-frame time percentiles of the RNNoise stage alone (bin/rnnoise_benchmark.rs:92-96).
+    The RNNoise stage runs its packed mixed-radix transforms (afo_rnn_fft_mode = 1, same results to the last bits)."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+
     sys.path.insert(0, str(ROOT / "oracle"))
     import af_oracle_py as oracle  # the checker / baseline, never the product path
     from signals import kat_signal, stream_params
 
-    n_blocks = int(seconds * 100)
     settings = dict(CHAIN_SETTINGS)
-    frames = 0
-    elapsed = 0.0
-    streams = 0
-    oracle.simulate_auto_eq_chain(kat_signal(20), SAMPLE_RATE, BANDS, settings)  # warm-up
-    while elapsed < budget_s and streams < 64:
-        st, f0, ph = stream_params(streams)
+    lib = oracle.lib()
+    ctypes.c_int.in_dll(lib, "afo_rnn_fft_mode").value = 1
+
+    def run_stream(index: int, n_blocks: int) -> int:
+        st, f0, ph = stream_params(index)
         x = kat_signal(n_blocks, st, f0, ph)
-        t0 = time.perf_counter()
         if full:
-            y = oracle.prefilter(x)
-            y = oracle.suppressor_process(y, 1.0, 0x5EED)
-            oracle.simulate_auto_eq_chain(y, SAMPLE_RATE, BANDS, settings)
-        else:
-            oracle.simulate_auto_eq_chain(x, SAMPLE_RATE, BANDS, settings)
-        elapsed += time.perf_counter() - t0
-        frames += x.size
-        streams += 1
+            x = oracle.suppressor_process(oracle.prefilter(x), 1.0, 0x5EED)
+        oracle.simulate_auto_eq_chain(x, SAMPLE_RATE, BANDS, settings)
+        return n_blocks * 480
+
+    try:
+        # ---- one thread, one stream
+        n_blocks = int(seconds * 100)
+        run_stream(0, 20)  # tables, page-in
+        run_stream(0, n_blocks)  # warm-up
+        times = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            frames = run_stream(0, n_blocks)
+            times.append(time.perf_counter() - t0)
+        single = {"value": frames / _percentile(times, 0.5), "unit": "frames/s", "cores": 1, "repetitions": 7,
+                  "median_s": _percentile(times, 0.5), "p95_s": _percentile(times, 0.95),
+                  "x_realtime": frames / _percentile(times, 0.5) / SAMPLE_RATE,
+                  "sample": f"1 stream x {seconds:g} s (S1), 1 warm-up + 7 repetitions"}
+        # ---- every host core: thread per stream shard
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        batch, shard_blocks = 256, 200
+        shards = [list(range(t, batch, threads)) for t in range(threads)]
+
+        def run_shard(idx_list):
+            return sum(run_stream(i, shard_blocks) for i in idx_list)
+
+        times = []
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            for rep in range(4):
+                t0 = time.perf_counter()
+                total = sum(pool.map(run_shard, shards))
+                if rep:
+                    times.append(time.perf_counter() - t0)
+        multi = {"value": total / _percentile(times, 0.5), "unit": "frames/s", "cores": threads, "repetitions": 3,
+                 "median_s": _percentile(times, 0.5), "x_realtime": total / _percentile(times, 0.5) / SAMPLE_RATE,
+                 "sample": f"{batch} streams x {shard_blocks / 100:g} s (S3), one shard per thread, 1 warm-up + 3 repetitions"}
+        # ---- RNNoise stage per frame
+        frame_stats = None
+        if full:
+            st = ctypes.create_string_buffer(1 << 18)
+            lib.afo_suppressor_init(st, 1.0, ctypes.c_uint64(0x5EED))
+            lib.afo_suppressor_process_frame.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+            x = kat_signal(600)
+            out = np.zeros(480, dtype=np.float32)
+            fp = ctypes.POINTER(ctypes.c_float)
+            per_frame = []
+            for f in range(600):
+                frame = np.ascontiguousarray(x[f * 480 : (f + 1) * 480])
+                t0 = time.perf_counter_ns()
+                lib.afo_suppressor_process_frame(st, out.ctypes.data_as(fp), frame.ctypes.data_as(fp))
+                per_frame.append((time.perf_counter_ns() - t0) * 1e-9)
+            per_frame = per_frame[100:]
+            frame_stats = {"frames": len(per_frame), "mean_s": float(np.mean(per_frame)), "p95_s": _percentile(per_frame, 0.95),
+                           "p99_s": _percentile(per_frame, 0.99), "max_s": float(np.max(per_frame)),
+                           "reference_published": "nnnoiseless 0.5.2 on Zen 4: 40.9 us/frame, p95 50.9, p99 70.0 (BASELINE.md)"}
+    finally:
+        ctypes.c_int.in_dll(lib, "afo_rnn_fft_mode").value = 0
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -132,10 +192,11 @@ def cpu_baseline(seconds: float, full: bool, budget_s: float = 15.0) -> dict:
     except OSError:
         pass
     return {
-        "value": frames / elapsed, "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"{streams} streams x {seconds:g} s of the same S3 workload, same chain ({'full' if full else 'dynamics'}), 1 thread; "
-                  "the RNNoise stage of this port uses a plain mixed-radix FFT (the reference crate measures 40.9 us/frame, BASELINE.md)",
-        "x_realtime": frames / elapsed / SAMPLE_RATE, "host_cpu": cpu_model, "host_cores": os.cpu_count(),
+        "value": multi["value"], "unit": "frames/s", "cores": multi["cores"], "kind": "port",
+        "sample": multi["sample"] + f"; same chain ({'full' if full else 'dynamics'}); CPU restatement of rust-core (oracle/), "
+                  "the Rust reference cannot be built offline",
+        "x_realtime": multi["x_realtime"], "single_thread": single, "all_cores": multi, "suppressor_per_frame": frame_stats,
+        "host_cpu": cpu_model, "host_cores": os.cpu_count(),
     }
 
 
@@ -309,17 +370,50 @@ def main() -> None:
     used = int(engine._lib.af_engine_last_kernel(engine._h))
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
     quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
-    split = float(np.mean(tail_ms)) > 0.0  # the chain ran as head + tail launches (af_ring_kernel.hip, kMode 1 / 2)
-    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}{',head' if split else ''}>",
-                   3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
+    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
     if rank == 0:
-        # dominant kernel: the chain launch (HIP events recorded by the engine around it on this stream)
-        # (with the suppressor on the chain runs once per 50-frame window, so a step holds several launches)
-        # (split chain: the dominant kernel is the head launch; the tail's launches are reported beside it)
+        # dominant kernel: the chain launch (HIP events recorded by the engine around it on the stream it runs on)
+        # (with the suppressor on the chain runs once per window, so a step holds several launches)
         launches = max(1, int(segments))
         avg_kernel_s = float(np.mean(first_ms)) / 1000.0 / launches
         frames_per_launch = streams * n // launches
         achieved = ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        chain_groups = (streams + 63) // 64 if used == 2 else ((streams + 15) // 16 if used == 3 else (streams + 63) // 64)
+        roofline = {
+            # scan/IIR/FIR work is priced against HBM by convention; what actually bounds this kernel is
+            # vector issue on the CUs its workgroups occupy (see `compute` below and DESIGN.md 4.3)
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
+            "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
+            "limiting_resource": "vector issue on the chain's CUs (serial recurrences: one 16-wave workgroup per 64 streams per CU)",
+        }
+        prof = profile_counters(full, streams, args.seconds)
+        if prof is not None:
+            row = next((v for k, v in prof["kernels"].items() if kernel_name.split("<")[0] in k), None)
+            if row is not None:
+                per_launch = row["launches_per_step"]
+                roofline["traffic"] = (row["fetch_bytes"] + row["write_bytes"]) / per_launch  # HBM bytes per launch (PMC)
+                cus = min(chain_groups, 256)
+                t_kernel = avg_kernel_s
+                roofline["compute"] = {
+                    "cus_used": cus, "waves_per_simd": 4 if used == 2 else None,
+                    "valu_insts_per_launch": row["valu_insts"] / per_launch,
+                    # wave-instructions issued / (CUs x 4 SIMDs x clock x time): one instruction per SIMD-cycle as the roof
+                    # (a SIMD-32 issues a wave64 f32 instruction over 2 cycles, an f64 one over 4)
+                    "valu_issue_frac": row["valu_insts"] / per_launch / (cus * 4 * CLOCK_HZ * t_kernel),
+                    "valu_issue_frac_whole_chip": row["valu_insts"] / per_launch / (256 * 4 * CLOCK_HZ * t_kernel),
+                    "achieved_f64_tflops": row.get("f64_flops", 0.0) / per_launch / t_kernel / 1e12,
+                    "peak_f64_tflops": 78.6,
+                }
+            roofline["step_traffic"] = {
+                "fetch_bytes": sum(v["fetch_bytes"] for v in prof["kernels"].values()),
+                "write_bytes": sum(v["write_bytes"] for v in prof["kernels"].values()),
+                "algorithmic_bytes": ALGORITHMIC_BYTES_PER_SAMPLE * streams * n,
+                "per_kernel": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in prof["kernels"].items()},
+            }
+            roofline["counters_from"] = {"file": "profiles/r02_step_counters.json", "commit": prof.get("commit"),
+                                         "note": "separate rocprofv3 --pmc runs of this command; not measured in this run"}
         line = {
             "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain",
             "value": value,
@@ -343,13 +437,7 @@ def main() -> None:
                 "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
                 "kernel": kernel_name, "sharding": f"streams x{world}, no data-path collective",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel_name, streams, n / launches),
-                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
-                "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
-                "tail_kernel_ms": float(np.mean(tail_ms)) / launches if split else None,
-            },
+            "roofline": roofline,
             "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),
                          "all_kernels": float(np.mean(kernel_ms))},
             "checks": {"output_rms": float(np.sqrt(merged["output_square_sum"] / (world * streams * n))),

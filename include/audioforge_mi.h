@@ -229,14 +229,6 @@ int64_t af_engine_samples_processed(const af_engine *e);
  * workgroup) wherever its LDS layout fits, AF_KERNEL_QUAD (16 streams per workgroup) for longer limiter lookaheads,
  * AF_KERNEL_LANE_PER_STREAM otherwise */
 int af_engine_set_kernel(af_engine *e, int32_t kernel);
-/* The token-ring chain can run each suppressor window as two launches on different CUs (head: front end, EQ,
- * compressor detector; tail: gain smoothing, limiter, true peak).  Results are bit-identical to the one-launch form;
- * it is off by default because both halves turn out bound by their longest token, not by issue slots. */
-int af_engine_set_chain_split(af_engine *e, int32_t on);
-/* With the suppressor on, the output-side TruePeakDetector (block_processor.rs:159) can run as a matrix-core kernel of
- * its own behind each chain window instead of inside the chain kernel: same block rows bit for bit, off by default
- * (the chain kernel turned out bound by its serial units, not by the detector's instructions). */
-int af_engine_set_detector_kernel(af_engine *e, int32_t on);
 /* AF_KERNEL_* the most recent chain launch used; VALUE, not a status */
 int af_engine_last_kernel(const af_engine *e);
 /* tuning of the token-ring kernel: wavefronts per 64-stream group and samples per chunk
@@ -248,8 +240,8 @@ int af_engine_set_timing_enabled(af_engine *e, int32_t enabled);
 int af_engine_last_kernel_ms(af_engine *e, double *ms, int32_t *launches);
 /* the same split at the suppressor | chain boundary (front-end pre-pass counts as suppressor time) */
 int af_engine_last_stage_ms(af_engine *e, double *suppressor_ms, double *chain_ms);
-/* chain launches of the last call: summed duration of the whole-chain (or split-chain head) launches, of the split
- * chain's tail launches (0 when the chain ran as one launch per segment), and the number of segments */
+/* chain launches of the last call: their summed duration and the number of segments (`tail_ms` is always 0: it belonged
+ * to a two-launch form of the chain that was measured slower and removed) */
 int af_engine_last_chain_launch_ms(af_engine *e, double *first_ms, double *tail_ms, int32_t *segments);
 
 /* ---- product resampler ------------------------------------------------------------------

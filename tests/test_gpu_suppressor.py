@@ -119,37 +119,6 @@ def test_a_ragged_call_returns_whole_frames(mi):
     eng.close()
 
 
-def test_split_chain_is_bit_identical_to_one_launch(mi):
-    """The two-launch form of the token-ring chain (head: EQ + compressor detector, tail: gain smoothing + limiter +
-    true peak, af_ring_kernel.hip kMode 1 / 2) against the one-launch form on the same engine configuration: audio and
-    every block row bit for bit, across two calls (state hand-over) and a ragged stream group."""
-    from mic_eq_mi import mic_eq_core as core
-
-    audio = S.batch_signal(70, 180)  # 70 streams (64 + 6), 1.8 s: several windows per call
-    settings = S.limiter_settings(2.0)
-    bands = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]
-
-    def run(split: int):
-        eng = core.Engine(48_000.0, audio.shape[0])
-        core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)  # legacy setters: a 72-sample crossfade is pending
-        eng.set_prefilter_enabled(1, 1)
-        eng.set_suppressor_enabled(1)
-        eng.set_chain_split(split)
-        a = eng.process(audio[:, : 110 * 480])
-        rows_a = eng.block_stats().copy()
-        b = eng.process(audio[:, 110 * 480 :])
-        rows_b = eng.block_stats().copy()
-        eng.close()
-        return np.concatenate([a, b], axis=1), rows_a, rows_b
-
-    y1, ra1, rb1 = run(1)
-    y0, ra0, rb0 = run(0)
-    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
-    assert ra1.tobytes() == ra0.tobytes()
-    assert rb1.tobytes() == rb0.tobytes()
-    assert float(np.abs(y1).max()) > 0.05
-
-
 def test_ramped_window_schedule_matches_restatement(mi, oracle):
     """A call long enough for the ramped window schedule (windows of 4, 8, 16, 20 ..., 16, 8, 4 frames,
     af_api.cpp) must give what frame-by-frame processing gives: the windows are an execution detail."""
@@ -157,50 +126,3 @@ def test_ramped_window_schedule_matches_restatement(mi, oracle):
     want = np.stack([oracle.suppressor_process(audio[s], 1.0, 0x5EED) for s in range(audio.shape[0])])
     got = mi.suppress(audio, 1.0, 0x5EED)
     _check(got, want)
-
-
-def test_output_true_peak_rows_from_the_detector_kernel(mi, oracle):
-    """With the suppressor on, the output-side TruePeakDetector (block_processor.rs:159, true_peak.rs:208-218) can run as
-    a matrix-core kernel of its own behind each chain window (af_truepeak.hip).  Its block rows must equal the oracle's
-    detector run over the GPU's own output audio, bit for bit: across windows, across calls (history hand-over), for a
-    ragged stream count, and with a non-finite-free but denormal-rich tail (a fade to digital silence)."""
-    import ctypes as C
-
-    from mic_eq_mi import mic_eq_core as core
-
-    audio = S.batch_signal(21, 240).copy()
-    audio[:, 200 * 480 :] *= np.linspace(1.0, 0.0, 40 * 480, dtype=np.float32) ** 8  # decays through tiny values
-    audio[3, 150 * 480 :] = 0.0
-    settings = S.limiter_settings(2.0)
-    bands = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]
-    eng = core.Engine(48_000.0, audio.shape[0])
-    core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)
-    eng.set_prefilter_enabled(1, 1)
-    eng.set_suppressor_enabled(1)
-    eng.set_detector_kernel(1)
-    outs, peaks = [], []
-    for lo, hi in ((0, 130 * 480), (130 * 480, 240 * 480)):
-        outs.append(eng.process(audio[:, lo:hi]))
-        peaks.append(eng.block_stats()["output_true_peak"].copy())  # [block][stream]
-    eng.close()
-    y = np.concatenate(outs, axis=1)
-    got = np.concatenate(peaks, axis=0)
-
-    L = oracle.lib()
-
-    class Detector(C.Structure):
-        _fields_ = [("history", C.c_float * 32), ("last_peak", C.c_float)]
-
-    L.afo_tp_detector_init.argtypes = [C.POINTER(Detector)]
-    L.afo_tp_detector_process_block.argtypes = [C.POINTER(Detector), C.POINTER(C.c_float), C.c_size_t]
-    L.afo_tp_detector_process_block.restype = C.c_float
-    cb = 960
-    assert got.shape == (y.shape[1] // cb, y.shape[0])
-    for s in range(y.shape[0]):
-        det = Detector()
-        L.afo_tp_detector_init(C.byref(det))
-        row = np.ascontiguousarray(y[s])
-        want = np.array([L.afo_tp_detector_process_block(C.byref(det), row[b * cb :].ctypes.data_as(C.POINTER(C.c_float)), cb)
-                         for b in range(y.shape[1] // cb)], dtype=np.float32)
-        assert np.array_equal(got[:, s].view(np.uint32), want.view(np.uint32)), (s, np.flatnonzero(got[:, s] != want)[:5])
-    assert float(got.max()) > 0.05
