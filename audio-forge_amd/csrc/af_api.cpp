@@ -67,8 +67,24 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+// one more chain preset of an engine (preset 0 is af_engine::proto / host_params)
+struct af_preset {
+  af::ChainProto proto;
+  af::ChainParams host_params{};
+  explicit af_preset(double fs) : proto(fs) {}
+};
+
 struct af_engine {
   af::ChainProto proto;
+  // Presets.  An engine is N streams in groups of 64 (one chain workgroup each); every group runs one preset.  Preset 0 is
+  // `proto`; af_engine_set_preset_count adds fresh ones, the setters address the selected one, af_engine_assign_presets
+  // maps groups to presets.  The device holds the parameter blocks as an array and a group -> preset table.
+  std::vector<af_preset> extra_presets;
+  int current_preset = 0;
+  std::vector<int32_t> group_preset;         // [ceil(n_streams / 64)], empty = every group runs preset 0
+  int32_t *d_group_preset = nullptr;
+  af::ChainParams *d_params_multi = nullptr;  // [1 + extra_presets.size()]
+  std::vector<af::ChainParams> uploaded_multi;
   int n_streams;
   int device;
   bool started = false;
@@ -141,6 +157,10 @@ int require_config(af_engine *e) {
   return AF_OK;
 }
 
+// the prototype the setters address
+af::ChainProto &cur(af_engine *e) { return e->current_preset == 0 ? e->proto : e->extra_presets[e->current_preset - 1].proto; }
+const af::ChainProto &cur(const af_engine *e) { return e->current_preset == 0 ? e->proto : e->extra_presets[e->current_preset - 1].proto; }
+
 int check_band(int32_t band) {
   if (band < 0 || band >= af::kNumBands) return fail(AF_ERR_INVALID_ARGUMENT, "band index %d out of range", band);
   return AF_OK;
@@ -151,9 +171,7 @@ af::EqBandConfig to_cfg(const af_eq_band_config &c) {
 }
 
 // Flatten the prototype into ChainParams (uniform) ...
-void export_params(af_engine *e) {
-  const af::ChainProto &p = e->proto;
-  af::ChainParams &o = e->host_params;
+void export_params(af_engine *e, const af::ChainProto &p, af::ChainParams &o) {
   std::memset(&o, 0, sizeof o);
   uint32_t f = 0;
   if (p.deesser_enabled) f |= af::kFlagDeesser;
@@ -185,15 +203,26 @@ void export_params(af_engine *e) {
   o.tp.ceiling_linear = tp.ceiling_linear;
   o.tp.release_coeff = tp.release_coeff;
 }
+void export_params(af_engine *e) {
+  export_params(e, e->proto, e->host_params);
+  for (af_preset &ps : e->extra_presets) export_params(e, ps.proto, ps.host_params);
+}
+const af::ChainProto &preset_proto(const af_engine *e, int k) { return k == 0 ? e->proto : e->extra_presets[k - 1].proto; }
+af::ChainParams &preset_params(af_engine *e, int k) { return k == 0 ? e->host_params : e->extra_presets[k - 1].host_params; }
+int preset_of_stream(const af_engine *e, int64_t s) { return e->group_preset.empty() ? 0 : e->group_preset[s / 64]; }
 
 // ... and the initial per-stream state planes.
 int upload_initial_state(af_engine *e) {
-  const af::ChainProto &p = e->proto;
   const int64_t B = e->n_streams;
-  const int nsec = e->host_params.n_eq_sections;
-  const int meter_slots = (p.compressor_enabled && p.compressor.auto_makeup_enabled) ? e->host_params.comp.meter_slots : 0;
-  const int n64 = af::f64_field_count(nsec, meter_slots);
-  const int n32 = af::f32_field_count(p.limiter.lookahead_samples);
+  const int n_presets = 1 + (int)e->extra_presets.size();
+  int n64 = 0, n32 = 0;
+  for (int k = 0; k < n_presets; ++k) {
+    const af::ChainProto &p = preset_proto(e, k);
+    const af::ChainParams &hp = preset_params(e, k);
+    const int meter_slots = (p.compressor_enabled && p.compressor.auto_makeup_enabled) ? hp.comp.meter_slots : 0;
+    n64 = std::max(n64, af::f64_field_count(hp.n_eq_sections, meter_slots));
+    n32 = std::max(n32, af::f32_field_count(p.limiter.lookahead_samples));
+  }
   if (e->d_st64 && (n64 != e->n_f64 || n32 != e->n_f32)) {
     AF_HIP(hipFree(e->d_st64));
     AF_HIP(hipFree(e->d_st32));
@@ -206,31 +235,38 @@ int upload_initial_state(af_engine *e) {
     e->n_f64 = n64;
     e->n_f32 = n32;
   }
-  std::vector<double> v64(n64, 0.0);
-  std::vector<float> v32(n32, 0.0f);
-  const af::CompressorProto &c = p.compressor;
-  v64[af::kCompPeakEnvDb] = -120.0;
-  v64[af::kCompGr] = c.current_gain_reduction_db;
-  v64[af::kCompFastEnv] = c.fast_release_env_db;
-  v64[af::kCompSlowEnv] = c.slow_release_env_db;
-  v64[af::kCompCurReleaseMs] = c.current_release_ms;
-  v64[af::kCompTargetReleaseMs] = c.target_release_ms;
-  // compressor.rs:760-761: release_coeff is tc(current_release_ms) from the first sample on
-  v64[af::kCompReleaseCoeff] = af::time_constant_to_coeff(c.current_release_ms, c.sample_rate);
-  v64[af::kCompSmoothedMakeup] = c.smoothed_makeup_gain;
-  v64[af::kCompCurrentLufs] = -100.0;
-  v64[af::kLimGain] = 1.0;
-  for (int i = 0; i < 3; ++i) {  // the dynamic EQ's coefficients are per-stream state (deesser.rs:536-538)
-    const af::BiquadCoef &c = e->host_params.deesser.bands[i].dynamic_eq.active;
-    double *d = &v64[af::kDeBand0 + i * af::kDeBandStride + 6];
-    d[0] = c.b0; d[1] = c.b1; d[2] = c.b2; d[3] = c.a1; d[4] = c.a2;
+  // every stream starts from its preset's prototype
+  std::vector<std::vector<double>> v64s(n_presets, std::vector<double>(n64, 0.0));
+  std::vector<std::vector<float>> v32s(n_presets, std::vector<float>(n32, 0.0f));
+  for (int k = 0; k < n_presets; ++k) {
+    std::vector<double> &v64 = v64s[k];
+    std::vector<float> &v32 = v32s[k];
+    const af::CompressorProto &c = preset_proto(e, k).compressor;
+    v64[af::kCompPeakEnvDb] = -120.0;
+    v64[af::kCompGr] = c.current_gain_reduction_db;
+    v64[af::kCompFastEnv] = c.fast_release_env_db;
+    v64[af::kCompSlowEnv] = c.slow_release_env_db;
+    v64[af::kCompCurReleaseMs] = c.current_release_ms;
+    v64[af::kCompTargetReleaseMs] = c.target_release_ms;
+    // compressor.rs:760-761: release_coeff is tc(current_release_ms) from the first sample on
+    v64[af::kCompReleaseCoeff] = af::time_constant_to_coeff(c.current_release_ms, c.sample_rate);
+    v64[af::kCompSmoothedMakeup] = c.smoothed_makeup_gain;
+    v64[af::kCompCurrentLufs] = -100.0;
+    v64[af::kLimGain] = 1.0;
+    for (int i = 0; i < 3; ++i) {  // the dynamic EQ's coefficients are per-stream state (deesser.rs:536-538)
+      const af::BiquadCoef &bc = preset_params(e, k).deesser.bands[i].dynamic_eq.active;
+      double *d = &v64[af::kDeBand0 + i * af::kDeBandStride + 6];
+      d[0] = bc.b0; d[1] = bc.b1; d[2] = bc.b2; d[3] = bc.a1; d[4] = bc.a2;
+    }
+    v32[af::kTpGain] = 1.0f;
   }
-  v32[af::kTpGain] = 1.0f;
-  // broadcast: every stream starts from the prototype
   std::vector<double> plane64((size_t)n64 * B);
   std::vector<float> plane32((size_t)n32 * B);
-  for (int f = 0; f < n64; ++f) std::fill_n(plane64.begin() + (size_t)f * B, B, v64[f]);
-  for (int f = 0; f < n32; ++f) std::fill_n(plane32.begin() + (size_t)f * B, B, v32[f]);
+  for (int64_t st = 0; st < B; ++st) {
+    const int k = preset_of_stream(e, st);
+    for (int f = 0; f < n64; ++f) plane64[(size_t)f * B + st] = v64s[k][f];
+    for (int f = 0; f < n32; ++f) plane32[(size_t)f * B + st] = v32s[k][f];
+  }
   AF_HIP(hipMemcpy(e->d_st64, plane64.data(), plane64.size() * sizeof(double), hipMemcpyHostToDevice));
   AF_HIP(hipMemcpy(e->d_st32, plane32.data(), plane32.size() * sizeof(float), hipMemcpyHostToDevice));
   return AF_OK;
@@ -252,6 +288,32 @@ int ensure_started(af_engine *e) {
                                         "(e.g. 480 or 960 samples at 48 kHz) and a sample rate the meter supports");
       if (e->host_params.control_block < 64)
         return fail(AF_ERR_UNSUPPORTED, "auto-makeup needs control blocks of at least 64 samples");
+    }
+    if (!e->extra_presets.empty()) {
+      // several presets in one engine: the plain one-launch form of the token-ring kernel serves them (the workgroup of a
+      // 64-stream group reads its own parameter block); what shapes the launch itself must agree across presets
+      for (const af_preset &ps : e->extra_presets) {
+        if (ps.host_params.control_block != e->host_params.control_block)
+          return fail(AF_ERR_INVALID_ARGUMENT, "every preset of an engine must use the same control block");
+        if (ps.proto.sample_rate != e->proto.sample_rate) return fail(AF_ERR_INVALID_ARGUMENT, "presets must share the sample rate");
+      }
+      for (int k = 0; k <= (int)e->extra_presets.size(); ++k) {
+        const af::ChainParams &hp = preset_params(e, k);
+        if ((hp.flags & af::kFlagDeesser) || ((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled))
+          return fail(AF_ERR_UNSUPPORTED, "the de-esser and auto-makeup passes are built for single-preset engines only");
+      }
+      if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED)
+        return fail(AF_ERR_UNSUPPORTED, "multi-preset engines run the token-ring kernel");
+      const size_t n_groups = (size_t)(e->n_streams + 63) / 64;
+      if (e->group_preset.size() != n_groups) e->group_preset.assign(n_groups, 0);
+      if (e->d_group_preset) AF_HIP(hipFree(e->d_group_preset));
+      if (e->d_params_multi) AF_HIP(hipFree(e->d_params_multi));
+      e->d_group_preset = nullptr;
+      e->d_params_multi = nullptr;
+      AF_HIP(hipMalloc(&e->d_group_preset, sizeof(int32_t) * n_groups));
+      AF_HIP(hipMemcpy(e->d_group_preset, e->group_preset.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
+      AF_HIP(hipMalloc(&e->d_params_multi, sizeof(af::ChainParams) * (1 + e->extra_presets.size())));
+      e->uploaded_multi.clear();
     }
     if (!e->d_params) AF_HIP(hipMalloc(&e->d_params, sizeof(af::ChainParams)));
     if (!e->d_params_pre) AF_HIP(hipMalloc(&e->d_params_pre, sizeof(af::ChainParams)));
@@ -285,7 +347,8 @@ int check_device_status(af_engine *e) {
 
 // after a launch of n samples: advance the (stream-uniform) crossfade counters
 void advance_crossfades(af_engine *e, int64_t n) {
-  af::ChainParams &o = e->host_params;
+ for (int preset = 0; preset <= (int)e->extra_presets.size(); ++preset) {
+  af::ChainParams &o = preset_params(e, preset);
   std::vector<af::SectionParams *> sections;
   for (int k = 0; k < o.n_eq_sections; ++k) sections.push_back(&o.eq[k]);
   if (o.flags & af::kFlagDeesser)
@@ -307,6 +370,66 @@ void advance_crossfades(af_engine *e, int64_t n) {
       e->params_dirty = true;
     }
   }
+ }
+}
+
+// Several presets in one engine: one launch of the token-ring kernel, the workgroup of every 64-stream group reading its
+// own parameter block.  `strip` = flags the caller's pipeline has already taken care of (the suppressor's front end).
+int launch_chain_multi(af_engine *e, uint32_t strip, const float *in, float *out, int64_t n_samples, int64_t stream_stride,
+                       int32_t layout, int64_t samples_before, af::BlockStats *stats, hipStream_t stream) {
+  const int n_presets = 1 + (int)e->extra_presets.size();
+  std::vector<af::ChainParams> runs((size_t)n_presets);
+  size_t dyn_sections = 0;
+  int max_sections = 0, max_lookahead = 0;
+  bool any_xf = false;
+  for (int k = 0; k < n_presets; ++k) {
+    runs[k] = preset_params(e, k);
+    runs[k].flags &= ~strip;
+    max_sections = std::max(max_sections, runs[k].n_eq_sections);
+    max_lookahead = std::max(max_lookahead, runs[k].lim.lookahead_samples);
+    for (int j = 0; j < runs[k].n_eq_sections; ++j) any_xf |= runs[k].eq[j].xf_remaining > 0;
+  }
+  (void)dyn_sections;
+  if (af::ring_kernel_dynamic_lds(max_sections, max_lookahead, any_xf) > af::kMaxLdsBytes)
+    return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for one of the presets");
+  e->last_kernel_used = AF_KERNEL_PHASED;
+  const int cb = runs[0].control_block;
+  const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
+  if (e->uploaded_multi.size() != runs.size() ||
+      std::memcmp(e->uploaded_multi.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
+    e->uploaded_multi = runs;  // engine-owned copy: stays valid until the async copy has run
+    AF_HIP(hipMemcpyAsync(e->d_params_multi, e->uploaded_multi.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
+    AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+  }
+  af::LaunchArgs a{};
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.in = in;
+  a.out = out;
+  a.stats = stats;
+  a.status = e->d_status;
+  a.params = e->d_params_multi;
+  a.group_preset = e->d_group_preset;
+  a.n_samples = n_samples;
+  a.stream_stride = stream_stride;
+  a.samples_before = samples_before;
+  a.n_streams = e->n_streams;
+  a.layout = layout;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  if (e->timing) {
+    AF_HIP(hipEventCreate(&t0));
+    AF_HIP(hipEventCreate(&t1));
+    AF_HIP(hipEventRecord(t0, stream));
+  }
+  AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));  // fields are written by their tokens
+  AF_HIP(af::launch_chain_ring(a, max_sections, max_lookahead, any_xf, e->ring_variant, false, stream));
+  e->last_launches += 1;
+  if (e->timing) {
+    AF_HIP(hipEventRecord(t1, stream));
+    e->chain_ms_events.push_back({t0, t1});
+  }
+  advance_crossfades(e, n_samples);
+  return AF_OK;
 }
 
 // One pass of the chain over a segment of samples for every stream: one launch, or the pre-pass + main
@@ -315,6 +438,9 @@ void advance_crossfades(af_engine *e, int64_t n) {
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
                          af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/) {
+  if (!e->extra_presets.empty())
+    return launch_chain_multi(e, e->host_params.flags & ~run_in.flags, in, out, n_samples, stream_stride, layout, samples_before,
+                              stats, stream);
   af::ChainParams run = run_in;
   const int cb = run.control_block;
   const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
@@ -495,7 +621,7 @@ int af_engine_create(double sample_rate, int32_t n_streams, int32_t device, af_e
 
 void af_engine_destroy(af_engine *e) {
   if (!e) return;
-  if (e->d_params || e->d_st64 || e->d_stats || e->d_io || e->d_pending || e->d_asm || e->d_trace) {
+  if (e->d_params || e->d_st64 || e->d_stats || e->d_io || e->d_pending || e->d_asm || e->d_trace || e->d_group_preset || e->d_params_multi) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(e->d_params);
@@ -510,6 +636,8 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_status);
     (void)hipFree(e->d_io);
     (void)hipFree(e->d_pending);
+    (void)hipFree(e->d_group_preset);
+    (void)hipFree(e->d_params_multi);
     (void)hipFree(e->d_asm);
     (void)hipFree(e->d_trace);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -557,39 +685,45 @@ int32_t af_engine_n_streams(const af_engine *e) { return e ? e->n_streams : 0; }
     return AF_OK;                    \
   } while (0)
 
-int af_engine_set_deesser_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.deesser_enabled = e->proto.deesser.enabled = on != 0); }
-int af_engine_set_eq_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.eq_enabled = e->proto.eq.enabled = on != 0); }
-int af_engine_set_compressor_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor_enabled = e->proto.compressor.enabled = on != 0); }
-int af_engine_set_limiter_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.limiter_enabled = e->proto.limiter.enabled = on != 0); }
-int af_engine_set_eq_before_deesser(af_engine *e, int32_t on) { AF_SETTER(e->proto.eq_before_deesser = on != 0); }
-int af_engine_set_input_scrub_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.input_scrub = on != 0); }
-int af_engine_set_input_clamp_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.input_clamp = on != 0); }
+int af_engine_set_deesser_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).deesser_enabled = cur(e).deesser.enabled = on != 0); }
+int af_engine_set_eq_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).eq_enabled = cur(e).eq.enabled = on != 0); }
+int af_engine_set_compressor_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).compressor_enabled = cur(e).compressor.enabled = on != 0); }
+int af_engine_set_limiter_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).limiter_enabled = cur(e).limiter.enabled = on != 0); }
+int af_engine_set_eq_before_deesser(af_engine *e, int32_t on) { AF_SETTER(cur(e).eq_before_deesser = on != 0); }
+// the front end belongs to the engine, not to a preset (with the suppressor on it runs in the suppressor's pre-pass)
+#define AF_ALL_PRESETS(stmt)                                     \
+  do {                                                           \
+    { af::ChainProto &p = e->proto; stmt; }                      \
+    for (af_preset &ps__ : e->extra_presets) { af::ChainProto &p = ps__.proto; stmt; } \
+  } while (0)
+int af_engine_set_input_scrub_enabled(af_engine *e, int32_t on) { AF_SETTER(AF_ALL_PRESETS(p.input_scrub = on != 0)); }
+int af_engine_set_input_clamp_enabled(af_engine *e, int32_t on) { AF_SETTER(AF_ALL_PRESETS(p.input_clamp = on != 0)); }
 int af_engine_set_prefilter_enabled(af_engine *e, int32_t on, int32_t hp) {
-  AF_SETTER((e->proto.dc_block = on != 0, e->proto.pre_highpass = on != 0 && hp != 0));
+  AF_SETTER(AF_ALL_PRESETS((p.dc_block = on != 0, p.pre_highpass = on != 0 && hp != 0)));
 }
 int af_engine_set_control_block_samples(af_engine *e, int32_t n) {
   if (n < 1 || n > 8192) return fail(AF_ERR_INVALID_ARGUMENT, "control block must be in [1, 8192] samples");
-  AF_SETTER(e->proto.control_block = n);
+  AF_SETTER(AF_ALL_PRESETS(p.control_block = n));
 }
 
 int af_eq_set_band_frequency(af_engine *e, int32_t band, double hz) {
   if (int rc = check_band(band)) return rc;
-  AF_SETTER(e->proto.eq.set_band_frequency(band, hz));
+  AF_SETTER(cur(e).eq.set_band_frequency(band, hz));
 }
 int af_eq_set_band_gain(af_engine *e, int32_t band, double db) {
   if (int rc = check_band(band)) return rc;
-  AF_SETTER(e->proto.eq.set_band_gain(band, db));
+  AF_SETTER(cur(e).eq.set_band_gain(band, db));
 }
 int af_eq_set_band_q(af_engine *e, int32_t band, double q) {
   if (int rc = check_band(band)) return rc;
-  AF_SETTER(e->proto.eq.set_band_q(band, q));
+  AF_SETTER(cur(e).eq.set_band_q(band, q));
 }
 int af_eq_set_band_config(af_engine *e, int32_t band, const af_eq_band_config *c) {
   if (int rc = check_band(band)) return rc;
   if (!c) return fail(AF_ERR_INVALID_ARGUMENT, "config is null");
-  AF_SETTER(e->proto.eq.set_band_config(band, to_cfg(*c)));
+  AF_SETTER(cur(e).eq.set_band_config(band, to_cfg(*c)));
 }
-int af_eq_reset(af_engine *e) { AF_SETTER(e->proto.eq.reset()); }
+int af_eq_reset(af_engine *e) { AF_SETTER(cur(e).eq.reset()); }
 int af_eq_band_config_validate(const af_eq_band_config *c, int32_t index, double sample_rate) {
   if (!c) return fail(AF_ERR_INVALID_ARGUMENT, "config is null");
   if (c->filter_type < 0 || c->filter_type > 5)
@@ -599,18 +733,18 @@ int af_eq_band_config_validate(const af_eq_band_config *c, int32_t index, double
   return AF_OK;
 }
 
-int af_compressor_set_threshold(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_threshold(v)); }
-int af_compressor_set_ratio(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_ratio(v)); }
-int af_compressor_set_attack_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_attack_time(v)); }
-int af_compressor_set_release_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_release_time(v)); }
-int af_compressor_set_makeup_gain(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_makeup_gain(v)); }
-int af_compressor_set_adaptive_release(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_adaptive_release(on != 0)); }
-int af_compressor_set_base_release_time(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_base_release_time(v)); }
-int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_auto_makeup_enabled(on != 0)); }
-int af_compressor_set_target_lufs(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_target_lufs(v)); }
-int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.compressor.set_sidechain_highpass_enabled(on != 0)); }
+int af_compressor_set_threshold(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_threshold(v)); }
+int af_compressor_set_ratio(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_ratio(v)); }
+int af_compressor_set_attack_time(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_attack_time(v)); }
+int af_compressor_set_release_time(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_release_time(v)); }
+int af_compressor_set_makeup_gain(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_makeup_gain(v)); }
+int af_compressor_set_adaptive_release(af_engine *e, int32_t on) { AF_SETTER(cur(e).compressor.set_adaptive_release(on != 0)); }
+int af_compressor_set_base_release_time(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_base_release_time(v)); }
+int af_compressor_set_auto_makeup_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).compressor.set_auto_makeup_enabled(on != 0)); }
+int af_compressor_set_target_lufs(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_target_lufs(v)); }
+int af_compressor_set_sidechain_highpass_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).compressor.set_sidechain_highpass_enabled(on != 0)); }
 
-int af_compressor_set_noise_reference_reliability(af_engine *e, double v) { AF_SETTER(e->proto.compressor.set_noise_reference_reliability(v)); }
+int af_compressor_set_noise_reference_reliability(af_engine *e, double v) { AF_SETTER(cur(e).compressor.set_noise_reference_reliability(v)); }
 
 int af_compressor_set_activity_evidence(af_engine *e, const double *vad_probabilities, int64_t n_blocks, int32_t per_stream,
                                         double vad_reliability, double noise_floor_db, double live_noise_reliability) {
@@ -647,23 +781,23 @@ int af_compressor_set_activity_evidence(af_engine *e, const double *vad_probabil
   return AF_OK;
 }
 
-int af_limiter_set_ceiling(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_ceiling(v)); }
-int af_limiter_set_release_time(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_release_time(v)); }
-int af_limiter_set_lookahead_ms(af_engine *e, double v) { AF_SETTER(e->proto.limiter.set_lookahead_ms(v)); }
-double af_limiter_ceiling_db(const af_engine *e) { return e ? e->proto.limiter.ceiling_db : 0.0; }
-int32_t af_limiter_lookahead_samples(const af_engine *e) { return e ? e->proto.limiter.lookahead_samples : 0; }
+int af_limiter_set_ceiling(af_engine *e, double v) { AF_SETTER(cur(e).limiter.set_ceiling(v)); }
+int af_limiter_set_release_time(af_engine *e, double v) { AF_SETTER(cur(e).limiter.set_release_time(v)); }
+int af_limiter_set_lookahead_ms(af_engine *e, double v) { AF_SETTER(cur(e).limiter.set_lookahead_ms(v)); }
+double af_limiter_ceiling_db(const af_engine *e) { return e ? cur(e).limiter.ceiling_db : 0.0; }
+int32_t af_limiter_lookahead_samples(const af_engine *e) { return e ? cur(e).limiter.lookahead_samples : 0; }
 
-int af_true_peak_limiter_set_release_ms(af_engine *e, float ms) { AF_SETTER(e->proto.tp_limiter.set_release_ms(ms)); }
+int af_true_peak_limiter_set_release_ms(af_engine *e, float ms) { AF_SETTER(cur(e).tp_limiter.set_release_ms(ms)); }
 
-int af_deesser_set_auto_enabled(af_engine *e, int32_t on) { AF_SETTER(e->proto.deesser.auto_enabled = on != 0); }
-int af_deesser_set_auto_amount(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_auto_amount(v)); }
-int af_deesser_set_low_cut_hz(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_low_cut_hz(v)); }
-int af_deesser_set_high_cut_hz(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_high_cut_hz(v)); }
-int af_deesser_set_threshold_db(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_threshold_db(v)); }
-int af_deesser_set_ratio(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_ratio(v)); }
-int af_deesser_set_attack_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_attack_ms(v)); }
-int af_deesser_set_release_ms(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_release_ms(v)); }
-int af_deesser_set_max_reduction_db(af_engine *e, double v) { AF_SETTER(e->proto.deesser.set_max_reduction_db(v)); }
+int af_deesser_set_auto_enabled(af_engine *e, int32_t on) { AF_SETTER(cur(e).deesser.auto_enabled = on != 0); }
+int af_deesser_set_auto_amount(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_auto_amount(v)); }
+int af_deesser_set_low_cut_hz(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_low_cut_hz(v)); }
+int af_deesser_set_high_cut_hz(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_high_cut_hz(v)); }
+int af_deesser_set_threshold_db(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_threshold_db(v)); }
+int af_deesser_set_ratio(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_ratio(v)); }
+int af_deesser_set_attack_ms(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_attack_ms(v)); }
+int af_deesser_set_release_ms(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_release_ms(v)); }
+int af_deesser_set_max_reduction_db(af_engine *e, double v) { AF_SETTER(cur(e).deesser.set_max_reduction_db(v)); }
 
 // ---- RNNoise suppressor (rust-core/src/dsp/rnnoise.rs) ----
 int af_engine_set_suppressor_enabled(af_engine *e, int32_t on) { AF_SETTER(e->supp.enabled = on != 0); }
@@ -694,6 +828,44 @@ int af_suppressor_debug_read(af_engine *e, int32_t frame, int32_t stream, float 
   AF_HIP(hipMemcpy(rec_out, e->supp.d_rec + cell, sizeof(af::SuppFrameRec), hipMemcpyDeviceToHost));
   if (x_out) AF_HIP(hipMemcpy(x_out, e->supp.d_X + cell * af::kRnnFreq, sizeof(float2) * af::kRnnFreq, hipMemcpyDeviceToHost));
   if (p_out) AF_HIP(hipMemcpy(p_out, e->supp.d_P + cell * af::kRnnFreq, sizeof(float2) * af::kRnnFreq, hipMemcpyDeviceToHost));
+  return AF_OK;
+}
+
+// ---- presets: several chain configurations in one engine, one per 64-stream group
+int af_engine_set_preset_count(af_engine *e, int32_t n) {
+  if (n < 1 || n > 256) return fail(AF_ERR_INVALID_ARGUMENT, "preset count must be in [1, 256]");
+  if (int rc = require_config(e)) return rc;
+  while ((int)e->extra_presets.size() > n - 1) e->extra_presets.pop_back();
+  while ((int)e->extra_presets.size() < n - 1) {  // a fresh OfflineDspBlockProcessor::new(sample_rate), block_processor.rs:46-60
+    e->extra_presets.emplace_back(e->proto.sample_rate);
+    af::ChainProto &np = e->extra_presets.back().proto;
+    np.control_block = e->proto.control_block;
+    np.input_scrub = e->proto.input_scrub;
+    np.input_clamp = e->proto.input_clamp;
+    np.dc_block = e->proto.dc_block;
+    np.pre_highpass = e->proto.pre_highpass;
+  }
+  if (e->current_preset >= n) e->current_preset = 0;
+  for (int32_t &g : e->group_preset)
+    if (g >= n) g = 0;
+  return AF_OK;
+}
+int32_t af_engine_preset_count(const af_engine *e) { return e ? 1 + (int32_t)e->extra_presets.size() : 0; }
+int af_engine_select_preset(af_engine *e, int32_t preset) {
+  if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
+  if (preset < 0 || preset > (int32_t)e->extra_presets.size()) return fail(AF_ERR_INVALID_ARGUMENT, "preset %d does not exist", preset);
+  e->current_preset = preset;
+  return AF_OK;
+}
+int af_engine_assign_presets(af_engine *e, const int32_t *preset_of_group, int32_t n_groups) {
+  if (!e || !preset_of_group) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_groups != (e->n_streams + 63) / 64)
+    return fail(AF_ERR_INVALID_ARGUMENT, "expected one preset index per group of 64 streams (%d), got %d", (e->n_streams + 63) / 64, n_groups);
+  for (int32_t g = 0; g < n_groups; ++g)
+    if (preset_of_group[g] < 0 || preset_of_group[g] > (int32_t)e->extra_presets.size())
+      return fail(AF_ERR_INVALID_ARGUMENT, "group %d: preset %d does not exist", g, preset_of_group[g]);
+  if (int rc = require_config(e)) return rc;
+  e->group_preset.assign(preset_of_group, preset_of_group + n_groups);
   return AF_OK;
 }
 
@@ -1279,7 +1451,7 @@ int af_eq_magnitude_response_v2(const double *freqs, size_t n, const af_eq_band_
 
 int af_engine_eq_magnitude_response(const af_engine *e, const double *freqs, size_t n, double *out_db) {
   if (!e || (!freqs && n) || (!out_db && n)) return fail(AF_ERR_INVALID_ARGUMENT, "null argument");
-  for (size_t i = 0; i < n; ++i) out_db[i] = e->proto.eq.magnitude_db(freqs[i]);
+  for (size_t i = 0; i < n; ++i) out_db[i] = cur(e).eq.magnitude_db(freqs[i]);
   return AF_OK;
 }
 

@@ -157,7 +157,8 @@ struct BlockStats {
 };
 
 struct LaunchArgs {
-  const ChainParams *params;  // device
+  const ChainParams *params;  // device; an array when `group_preset` is set
+  const int32_t *group_preset;  // device, [ceil(n_streams / 64)]: the parameter block of each 64-stream group, or null (all use [0])
   double *st64;               // [f64 fields][n_streams]
   float *st32;                // [f32 fields][n_streams]
   const float *in;

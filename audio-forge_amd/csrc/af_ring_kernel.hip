@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   // The parameter block is a kernel argument of its own, `const __restrict__`: nothing this kernel stores can alias it, so
   // its fields are uniform scalar loads (through the scalar cache).  As a pointer inside LaunchArgs every field read was a
   // global load behind an s_waitcnt vmcnt(0), most of them inside serial units (204 -> 37 global loads in the ISA).
-  const ChainParams &P = *params;
+  const ChainParams &P = params[a.group_preset ? a.group_preset[blockIdx.x] : 0];  // the preset of this 64-stream group
   const uint32_t flags = P.flags;
   const int nsec = (flags & kFlagEq) ? P.n_eq_sections : 0;
   const int n_groups = (nsec + kEqGroup - 1) / kEqGroup;

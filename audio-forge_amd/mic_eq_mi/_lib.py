@@ -157,6 +157,10 @@ SIGNATURES = {
     "af_engine_last_block_count": (_i64, [_vp]),
     "af_engine_read_block_stats": (C.c_int, [_vp, C.POINTER(BlockStats), _i64]),
     "af_engine_samples_processed": (_i64, [_vp]),
+    "af_engine_set_preset_count": (C.c_int, [_vp, _i32]),
+    "af_engine_preset_count": (_i32, [_vp]),
+    "af_engine_select_preset": (C.c_int, [_vp, _i32]),
+    "af_engine_assign_presets": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "af_engine_set_kernel": (C.c_int, [_vp, _i32]),
     "af_engine_set_ring_variant": (C.c_int, [_vp, _i32, _i32]),
     "af_engine_set_timing_enabled": (C.c_int, [_vp, _i32]),
@@ -188,7 +192,13 @@ SIGNATURES = {
 VALUE_FUNCTIONS = {
     "af_version", "af_last_error", "af_device_count", "af_engine_n_streams", "af_limiter_ceiling_db",
     "af_limiter_lookahead_samples", "af_suppressor_latency_samples", "af_engine_last_block_count", "af_engine_samples_processed", "af_engine_destroy", "af_engine_last_kernel",
-    "af_engine_pending_input", "af_engine_last_output_samples", "af_suppressor_trace_frames",
+    "af_engine_pending_input", "af_engine_last_output_samples", "af_suppressor_trace_frames", "af_engine_preset_count",
+    "af_noise_model_id", "af_noise_model_display_name", "af_noise_model_available", "af_noise_suppressor_destroy",
+    "af_noise_suppressor_engine", "af_noise_suppressor_push_samples", "af_noise_suppressor_available_samples",
+    "af_noise_suppressor_pending_input", "af_noise_suppressor_pop_samples_into", "af_noise_suppressor_drain_pending_input",
+    "af_noise_suppressor_get_strength", "af_noise_suppressor_is_enabled", "af_noise_suppressor_model_type",
+    "af_noise_suppressor_latency_samples", "af_noise_suppressor_backend_available", "af_noise_suppressor_backend_failed",
+    "af_noise_suppressor_backend_error",
     "af_resampler_destroy", "af_resampler_output_delay", "af_resampler_expected_frames", "af_resampler_sinc_len",
 }
 

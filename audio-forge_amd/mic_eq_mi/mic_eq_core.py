@@ -400,36 +400,88 @@ def _block_lengths(n: int, block: int) -> np.ndarray:
     return np.asarray([block] * full + ([rest] if rest else []), dtype=np.int64)
 
 
-def simulate_auto_eq_chain_batch(audio: np.ndarray, sample_rate: float, bands: Sequence[tuple[float, float, float]],
-                                 settings: Mapping[str, object] | None = None, device: int = 0,
+GROUP_STREAMS = 64  # streams of one chain workgroup = the granularity of a preset
+
+
+def _is_preset_list(bands, settings) -> bool:
+    return isinstance(settings, (list, tuple)) or (len(bands) > 0 and isinstance(bands[0], (list, tuple)) and len(bands[0]) > 0
+                                                    and isinstance(bands[0][0], (list, tuple)))
+
+
+def simulate_auto_eq_chain_batch(audio: np.ndarray, sample_rate: float, bands, settings=None, device: int = 0,
                                  diagnostics: bool = True) -> tuple[np.ndarray, list[dict[str, Any]]]:
-    """Batched form: ``audio`` is [n_streams, n] float32; every stream uses the same preset.
+    """Batched form: ``audio`` is [n_streams, n] float32.
+
+    ``bands`` / ``settings`` are either one preset for every stream (the reference's arguments), or one entry per
+    stream (a list of 10-band lists / a list of settings dicts): the reference configures one processor per stream
+    (python/mic_eq/config_parts/settings.py:543-593).  Streams that share a preset are packed into groups of 64 (the unit
+    a preset applies to on the GPU; partial groups are padded with silent streams) and handed back in the caller's order.
 
     Returns (output [n_streams, n] float32, one reference-shaped dict per stream).
     """
     started = time.perf_counter()
     if not np.isfinite(sample_rate) or sample_rate <= 0.0:
         raise ValueError("sample_rate must be positive and finite")
-    if len(bands) != NUM_BANDS:
-        raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
     audio = np.ascontiguousarray(audio, dtype=np.float32)
     if audio.ndim != 2:
         raise TypeError("audio must be [n_streams, n_samples]")
     n_streams, n = audio.shape
-    engine = Engine(sample_rate, n_streams, device)
+    if not _is_preset_list(bands, settings):
+        if len(bands) != NUM_BANDS:
+            raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(bands)}")
+        presets = [(bands, settings)]
+        stream_preset = np.zeros(n_streams, dtype=np.int64)
+    else:
+        per_bands = list(bands) if (len(bands) and isinstance(bands[0][0], (list, tuple))) else [bands] * n_streams
+        per_settings = list(settings) if isinstance(settings, (list, tuple)) else [settings] * n_streams
+        if len(per_bands) != n_streams or len(per_settings) != n_streams:
+            raise ValueError(f"expected one preset per stream ({n_streams}), got {len(per_bands)} band lists and {len(per_settings)} settings")
+        presets, index, stream_preset = [], {}, np.zeros(n_streams, dtype=np.int64)
+        for s_i, (b, st) in enumerate(zip(per_bands, per_settings)):
+            if len(b) != NUM_BANDS:
+                raise ValueError(f"expected {NUM_BANDS} EQ bands, got {len(b)}")
+            key = (repr([tuple(x) for x in b]), repr(sorted((st or {}).items(), key=lambda kv: kv[0])))
+            if key not in index:
+                index[key] = len(presets)
+                presets.append((b, st))
+            stream_preset[s_i] = index[key]
+    # pack: streams of preset k -> whole groups of 64
+    order, group_preset = [], []
+    for k in range(len(presets)):
+        members = np.flatnonzero(stream_preset == k)
+        padded = -(-members.size // GROUP_STREAMS) * GROUP_STREAMS if len(presets) > 1 else members.size
+        order.extend(members.tolist() + [-1] * (padded - members.size))
+        group_preset.extend([k] * (-(-padded // GROUP_STREAMS)))
+    order = np.asarray(order, dtype=np.int64)
+    packed = np.zeros((order.size, n), dtype=np.float32)
+    packed[order >= 0] = audio[order[order >= 0]]
+    engine = Engine(sample_rate, int(order.size), device)
     try:
-        effective = configure_auto_eq_chain(engine, float(sample_rate), bands, settings)
-        output = engine.process(audio) if n else audio.copy()
+        effective = []
+        if len(presets) > 1:
+            engine.set_preset_count(len(presets))
+        for k, (b, st) in enumerate(presets):
+            if len(presets) > 1:
+                engine.select_preset(k)
+            effective.append(configure_auto_eq_chain(engine, float(sample_rate), b, st))
+        if len(presets) > 1:
+            gp = np.asarray(group_preset, dtype=np.int32)
+            _lib.check(engine._lib.af_engine_assign_presets(engine._h, gp.ctypes.data_as(C.POINTER(C.c_int32)), int(gp.size)))
+        packed_out = engine.process(packed) if n else packed.copy()
         rows = engine.block_stats()
     finally:
         engine.close()
+    output = np.empty_like(audio)
+    position = np.empty(n_streams, dtype=np.int64)
+    position[order[order >= 0]] = np.flatnonzero(order >= 0)
+    output[:] = packed_out[position]
     results: list[dict[str, Any]] = []
     if diagnostics:
         block = int(min(max(round(sample_rate * 0.020), 1), 8192))
         lengths = _block_lengths(n, block)
         runtime_ms = (time.perf_counter() - started) * 1000.0
-        for s in range(n_streams):
-            d = chain_diagnostics(rows[:, s], lengths, effective)
+        for s_i in range(n_streams):
+            d = chain_diagnostics(rows[:, position[s_i]], lengths, effective[int(stream_preset[s_i])])
             d["candidate_runtime_ms"] = runtime_ms
             results.append(d)
     return output, results

@@ -225,6 +225,17 @@ int64_t af_engine_last_block_count(const af_engine *e);
 int af_engine_read_block_stats(af_engine *e, af_block_stats *out, int64_t capacity);
 /* total samples per stream processed since create/reset */
 int64_t af_engine_samples_processed(const af_engine *e);
+/* ---- presets ---------------------------------------------------------------------
+ * The reference configures one processor per stream (python/mic_eq/config_parts/settings.py:543-593).  An engine runs its
+ * streams in groups of 64 (one chain workgroup each) and every group may run its own preset: add presets (each starts as a
+ * fresh OfflineDspBlockProcessor::new, block_processor.rs:46-60), select the one the chain / EQ / compressor / limiter /
+ * de-esser setters address, and map groups to presets (one index per 64 streams).  The control block, the front-end
+ * switches, the suppressor and the kernel choice stay engine-wide.  Multi-preset engines run the plain token-ring form:
+ * AF_ERR_UNSUPPORTED when a preset enables the de-esser or auto-makeup, or its limiter lookahead does not fit the ring. */
+int af_engine_set_preset_count(af_engine *e, int32_t n);
+int32_t af_engine_preset_count(const af_engine *e);  /* VALUE */
+int af_engine_select_preset(af_engine *e, int32_t preset);
+int af_engine_assign_presets(af_engine *e, const int32_t *preset_of_group, int32_t n_groups);
 /* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: AF_KERNEL_PHASED (the token ring, 64 streams per
  * workgroup) wherever its LDS layout fits, AF_KERNEL_QUAD (16 streams per workgroup) for longer limiter lookaheads,
  * AF_KERNEL_LANE_PER_STREAM otherwise */
