@@ -23,6 +23,7 @@ hipError_t launch_chain_lane(const LaunchArgs &args, int lookahead_samples, hipS
 size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
+hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
                              hipStream_t stream);
 size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
@@ -38,6 +39,8 @@ hipError_t launch_kweight_energy(const float *audio, double *partial, int32_t *n
 hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32, const float *in, float *out,
                           BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
+hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, float *audio,
+                              BlockStats *stats, int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
@@ -84,6 +87,9 @@ struct af_engine {
   std::vector<int32_t> group_preset;         // [ceil(n_streams / 64)], empty = every group runs preset 0
   int32_t *d_group_preset = nullptr;
   af::ChainParams *d_params_multi = nullptr;  // [1 + extra_presets.size()]
+  af::ChainParams *d_params_eq = nullptr;     // [1 + extra_presets.size()]: what the systolic EQ kernel reads (af_eq_systolic.hip)
+  std::vector<af::ChainParams> uploaded_eq;
+  int eq_params_presets = 0;
   std::vector<af::ChainParams> uploaded_multi;
   int n_streams;
   int device;
@@ -111,6 +117,7 @@ struct af_engine {
   af::ChainParams *d_params_pre = nullptr;
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
   hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
+  hipStream_t eq_stream = nullptr;         // the window's systolic EQ (af_eq_systolic.hip), behind its overlap-add, beside the next window's synthesis
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
   af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
   af::ChainParams *d_params_de = nullptr;  // the de-esser pass reads the unedited parameter block
@@ -375,22 +382,20 @@ void advance_crossfades(af_engine *e, int64_t n) {
 
 // Several presets in one engine: one launch of the token-ring kernel, the workgroup of every 64-stream group reading its
 // own parameter block.  `strip` = flags the caller's pipeline has already taken care of (the suppressor's front end).
-int launch_chain_multi(af_engine *e, uint32_t strip, const float *in, float *out, int64_t n_samples, int64_t stream_stride,
-                       int32_t layout, int64_t samples_before, af::BlockStats *stats, hipStream_t stream) {
+int launch_chain_multi(af_engine *e, uint32_t strip, uint32_t add, const float *in, float *out, int64_t n_samples,
+                       int64_t stream_stride, int32_t layout, int64_t samples_before, af::BlockStats *stats, hipStream_t stream,
+                       bool stats_cleared) {
   const int n_presets = 1 + (int)e->extra_presets.size();
   std::vector<af::ChainParams> runs((size_t)n_presets);
-  size_t dyn_sections = 0;
-  int max_sections = 0, max_lookahead = 0;
-  bool any_xf = false;
+  size_t dyn = 0;  // every workgroup lays out its own preset: the launch needs the largest of the layouts
   for (int k = 0; k < n_presets; ++k) {
     runs[k] = preset_params(e, k);
-    runs[k].flags &= ~strip;
-    max_sections = std::max(max_sections, runs[k].n_eq_sections);
-    max_lookahead = std::max(max_lookahead, runs[k].lim.lookahead_samples);
-    for (int j = 0; j < runs[k].n_eq_sections; ++j) any_xf |= runs[k].eq[j].xf_remaining > 0;
+    runs[k].flags = (runs[k].flags & ~strip) | add;
+    bool xf = false;
+    for (int j = 0; j < runs[k].n_eq_sections; ++j) xf |= runs[k].eq[j].xf_remaining > 0;
+    dyn = std::max(dyn, af::ring_kernel_dynamic_lds(runs[k].n_eq_sections, runs[k].lim.lookahead_samples, xf));
   }
-  (void)dyn_sections;
-  if (af::ring_kernel_dynamic_lds(max_sections, max_lookahead, any_xf) > af::kMaxLdsBytes)
+  if (dyn > af::kMaxLdsBytes)
     return fail(AF_ERR_UNSUPPORTED, "the token-ring kernel needs more LDS than a CU has for one of the presets");
   e->last_kernel_used = AF_KERNEL_PHASED;
   const int cb = runs[0].control_block;
@@ -421,8 +426,8 @@ int launch_chain_multi(af_engine *e, uint32_t strip, const float *in, float *out
     AF_HIP(hipEventCreate(&t1));
     AF_HIP(hipEventRecord(t0, stream));
   }
-  AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));  // fields are written by their tokens
-  AF_HIP(af::launch_chain_ring(a, max_sections, max_lookahead, any_xf, e->ring_variant, false, stream));
+  if (!stats_cleared) AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));  // fields are written by their tokens
+  AF_HIP(af::launch_chain_ring_lds(a, dyn, e->ring_variant, false, stream));
   e->last_launches += 1;
   if (e->timing) {
     AF_HIP(hipEventRecord(t1, stream));
@@ -437,10 +442,12 @@ int launch_chain_multi(af_engine *e, uint32_t strip, const float *in, float *out
 // `params_stream` is where parameter uploads are ordered; `stream` is where the kernels run.
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
-                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/) {
+                         af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/,
+                         bool stats_cleared = false) {
+  // `stats_cleared`: the rows were zeroed (and partly filled) by an earlier kernel of this window: do not clear them again
   if (!e->extra_presets.empty())
-    return launch_chain_multi(e, e->host_params.flags & ~run_in.flags, in, out, n_samples, stream_stride, layout, samples_before,
-                              stats, stream);
+    return launch_chain_multi(e, e->host_params.flags & ~run_in.flags, run_in.flags & af::kFlagInputDone, in, out, n_samples,
+                              stream_stride, layout, samples_before, stats, stream, stats_cleared);
   af::ChainParams run = run_in;
   const int cb = run.control_block;
   const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
@@ -526,7 +533,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   }
   if (kernel == AF_KERNEL_PHASED) {
     // the ring kernel writes each stats field from the token that owns it; untouched fields must read 0
-    AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));
+    if (!stats_cleared) AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));
     if (two_pass) {
       af::ChainParams pre = run, post = run;
       pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter)) | af::kFlagPrePass;
@@ -637,6 +644,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_io);
     (void)hipFree(e->d_pending);
     (void)hipFree(e->d_group_preset);
+    (void)hipFree(e->d_params_eq);
     (void)hipFree(e->d_params_multi);
     (void)hipFree(e->d_asm);
     (void)hipFree(e->d_trace);
@@ -646,8 +654,9 @@ void af_engine_destroy(af_engine *e) {
   }
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = nullptr;
+  if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = nullptr;
   if (e->fin_stream) (void)hipStreamDestroy(e->fin_stream);
+  if (e->eq_stream) (void)hipStreamDestroy(e->eq_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->pre_stream) (void)hipStreamDestroy(e->pre_stream);
@@ -1067,7 +1076,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->trace_frames = frames;
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = stream;
+    e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = stream;
     e->borrowed_streams = true;
   }
 
@@ -1095,9 +1104,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->eq_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -1110,6 +1120,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
   if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
+  if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
   static const bool split_synthesis = [] {  // AF_SYNTH_SPLIT=0: resynthesis + overlap-add stay behind the network on one stream
     const char *env = std::getenv("AF_SYNTH_SPLIT");
     return !env || std::atoi(env) != 0;
@@ -1118,6 +1129,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
   int64_t blocks_done = 0;
   size_t ev_index = 0;
+  static const bool eq_offload_env = [] {  // AF_EQ_OFFLOAD=0: the EQ stays inside the chain launches (A/B runs)
+    const char *env = std::getenv("AF_EQ_OFFLOAD");
+    return !env || std::atoi(env) != 0;
+  }();
+  const bool eq_offload = eq_offload_env && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) &&
+                          (e->ring_variant == 0 || e->ring_variant == 1604) && (run.flags & af::kFlagEq);
+  bool eq_needs_chain_done = true;  // (the previous call's last chain launch has ended: the caller's stream waited for it)
   auto next_event = [&](hipEvent_t *out_ev) -> int {
     if (ev_index == e->sync_events.size()) {
       hipEvent_t ev;
@@ -1136,6 +1154,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipStreamWaitEvent(e->ana_stream, ev, 0));
     if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
     if (fin && fin != stream) AF_HIP(hipStreamWaitEvent(fin, ev, 0));
+    if (e->eq_stream != stream) AF_HIP(hipStreamWaitEvent(e->eq_stream, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
@@ -1222,14 +1241,71 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (int rc = enqueue_pre(w + 2)) return rc;
     if (w + 1 < n_windows)
       if (int rc = enqueue_ana(w + 1)) return rc;
-    AF_HIP(hipStreamWaitEvent(e->aux_stream, syn_done[w], 0));
     const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
     static const bool diag_skip_chain = std::getenv("AF_DIAG_SKIP_CHAIN") != nullptr;  // timing experiments only
+    // ---- the window's EQ on the suppressor's side (af_eq_systolic.hip), when the chain's launch would be the plain
+    // one-launch form of the token-ring kernel and no coefficient crossfade is running
+    af::ChainParams run_w = run;
+    bool eq_offloaded = false;
+    if (eq_offload && !diag_skip_chain) {
+      const int n_presets = 1 + (int)e->extra_presets.size();
+      bool ok = true;
+      std::vector<af::ChainParams> runs_eq((size_t)n_presets);
+      for (int k = 0; k < n_presets && ok; ++k) {
+        runs_eq[k] = preset_params(e, k);
+        runs_eq[k].flags &= ~(e->host_params.flags & ~run.flags);  // what the pre-pass has taken over
+        const af::ChainParams &hp = runs_eq[k];
+        ok = !(hp.flags & af::kFlagDeesser) && !((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled) &&
+             hp.n_eq_sections <= 16 && !(hp.flags & (af::kFlagDcBlock | af::kFlagPreHighpass)) &&
+             af::ring_kernel_dynamic_lds(hp.n_eq_sections, hp.lim.lookahead_samples, false) <= af::kMaxLdsBytes;
+        for (int j = 0; j < hp.n_eq_sections; ++j) ok = ok && hp.eq[j].xf_remaining == 0;
+      }
+      if (ok) {
+        const hipStream_t es = e->eq_stream;  // behind the window's overlap-add, beside the next window's synthesis
+        AF_HIP(hipStreamWaitEvent(es, syn_done[w], 0));
+        if (!e->d_params_eq || e->eq_params_presets != n_presets) {
+          if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
+          e->d_params_eq = nullptr;
+          AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets));
+          e->eq_params_presets = n_presets;
+          e->uploaded_eq.clear();
+        }
+        if (e->uploaded_eq.size() != runs_eq.size() ||
+            std::memcmp(e->uploaded_eq.data(), runs_eq.data(), sizeof(af::ChainParams) * runs_eq.size()) != 0) {
+          e->uploaded_eq = runs_eq;
+          AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof(af::ChainParams) * runs_eq.size(), hipMemcpyHostToDevice, es));
+          AF_HIP(hipStreamSynchronize(es));  // rare: the first window that qualifies
+        }
+        if (eq_needs_chain_done) {  // the previous window's EQ ran inside its chain launch: that launch owns the memories until it ends
+          hipEvent_t chain_done;
+          if (int rc2 = next_event(&chain_done)) return rc2;
+          AF_HIP(hipEventRecord(chain_done, e->aux_stream));
+          AF_HIP(hipStreamWaitEvent(es, chain_done, 0));
+          eq_needs_chain_done = false;
+        }
+        af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
+        AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
+        AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, rows_w,
+                                      seg_n, stream_stride, e->n_streams, es));
+        e->last_launches += 1;
+        hipEvent_t eq_done;
+        if (int rc2 = next_event(&eq_done)) return rc2;
+        AF_HIP(hipEventRecord(eq_done, es));
+        AF_HIP(hipStreamWaitEvent(e->aux_stream, eq_done, 0));
+        run_w.flags = (run_w.flags & ~af::kFlagEq) | af::kFlagInputDone;
+        eq_offloaded = true;
+      }
+    }
+    if (!eq_offloaded) {
+      AF_HIP(hipStreamWaitEvent(e->aux_stream, syn_done[w], 0));
+      eq_needs_chain_done = true;
+    }
     int rc = AF_OK;
     if (!diag_skip_chain)
-      rc = launch_chain_segment(e, run, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
-                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream);
+      rc = launch_chain_segment(e, run_w, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
+                                e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream,
+                                eq_offloaded);
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);

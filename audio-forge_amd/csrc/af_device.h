@@ -97,6 +97,7 @@ enum ChainFlags : uint32_t {
   kFlagDcBlock = 1u << 7,      // routing.rs:826-843
   kFlagPreHighpass = 1u << 8,
   kFlagPrePass = 1u << 9,      // first of two launches: front end + EQ only, no detector, no compressor bookkeeping
+  kFlagInputDone = 1u << 10,   // the input unit's work (block input statistics) was done by another kernel (af_eq_systolic.hip)
 };
 
 struct ChainParams {

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       double target[kChunk];
 
       // =========================== token: input scrub, block input stats, DC block + fixed HP
+      if (!(flags & kFlagInputDone)) {
       token_wait(turn, kTokIn, q);
       {
         double in_sq = first_in_block ? 0.0 : L64(kR64InSq);
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
       }
       token_pass(turn, kTokIn, q);
+      }
 
       // =========================== tokens: EQ section groups (eq.rs:371-379, biquad.rs:263-327)
       for (int g = 0; g < n_groups; ++g) {
@@ -979,9 +981,13 @@ static hipError_t launch_variant(const LaunchArgs &args, size_t dyn, hipStream_t
 }
 
 // `variant` = waves * 100 + chunk; 0 picks the default
+hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream);
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream) {
-  const size_t dyn = ring_lds_bytes(n_sections, lookahead_samples, crossfade);
+  return launch_chain_ring_lds(args, ring_lds_bytes(n_sections, lookahead_samples, crossfade), variant, auto_makeup, stream);
+}
+// `dyn`: dynamic LDS of the launch (several presets: the largest of their layouts, every workgroup lays out its own)
+hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream) {
   if (auto_makeup) return launch_variant<8, 4, true>(args, dyn, stream);  // one build: 256 VGPRs, no spills
   switch (variant) {
     case 1604: return launch_variant<16, 4>(args, dyn, stream);

@@ -12,7 +12,7 @@ x = bench.synth_batch(B, blocks, 0, dev)
 y = torch.empty_like(x)
 n = x.shape[1]
 for name, eq, comp, lim in (("all", 1, 1, 1), ("eq", 1, 0, 0), ("comp", 0, 1, 0), ("limiter+tp", 0, 0, 1), ("none", 0, 0, 0),
-                            ("eq+comp", 1, 1, 0)):
+                            ("eq+comp", 1, 1, 0), ("comp+limiter+tp", 0, 1, 1)):
     eng = core.Engine(48000.0, B, 0)
     core.configure_auto_eq_chain(eng, 48000.0, bench.BANDS, bench.CHAIN_SETTINGS)
     eng.set_eq_enabled(eq); eng.set_compressor_enabled(comp); eng.set_limiter_enabled(lim)
