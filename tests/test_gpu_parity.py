@@ -27,13 +27,19 @@ def mi(request):
 
     import mic_eq_mi
 
+    previous = os.environ.get("AF_KERNEL_VARIANT")
     os.environ["AF_KERNEL_VARIANT"] = request.param
 
     assert mic_eq_mi.CORE_AVAILABLE, "HIP library missing: GPU tests never fall back to the CPU"
     from mic_eq_mi import _lib
 
     assert _lib.load().af_device_count() >= 1
-    return mic_eq_mi
+    yield mic_eq_mi
+    # the variant must not leak into the test modules that run after this one (they test the default routing)
+    if previous is None:
+        os.environ.pop("AF_KERNEL_VARIANT", None)
+    else:
+        os.environ["AF_KERNEL_VARIANT"] = previous
 
 
 def _err(a, b):
