@@ -22,9 +22,14 @@ MAX_RMS = 5e-8
 def mi(request):
     import mic_eq_mi
 
+    previous = os.environ.get("AF_KERNEL_VARIANT")
     os.environ["AF_KERNEL_VARIANT"] = request.param
     assert mic_eq_mi.CORE_AVAILABLE, "HIP library missing: GPU tests never fall back to the CPU"
-    return mic_eq_mi
+    yield mic_eq_mi
+    if previous is None:  # the override must not leak into the modules that run after this one
+        os.environ.pop("AF_KERNEL_VARIANT", None)
+    else:
+        os.environ["AF_KERNEL_VARIANT"] = previous
 
 
 def _err(a, b):
