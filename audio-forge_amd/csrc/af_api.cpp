@@ -15,6 +15,7 @@
 #include "af_device.h"
 #include "af_host.hpp"
 #include "af_resampler_host.hpp"
+#include "af_stages.h"
 #include "af_suppressor_host.hpp"
 
 namespace af {
@@ -39,10 +40,13 @@ hipError_t launch_kweight_energy(const float *audio, double *partial, int32_t *n
 hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32, const float *in, float *out,
                           BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
-hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, float *audio,
+hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               BlockStats *stats, int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
+
+// AUTO routes the configurations the stage pipeline serves to it
+constexpr bool kStagedByDefault = false;
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
 static_assert(sizeof(af_block_stats) == 72, "stats row size");
@@ -138,6 +142,7 @@ struct af_engine {
   hipStream_t pre_stream = nullptr;                      // the suppressor's sample-serial pre-pass, two windows ahead
   hipStream_t ana_stream = nullptr;                      // spectra + pitch, one window ahead
   std::vector<hipEvent_t> sync_events;
+  size_t ev_cursor = 0;                                  // next free entry of sync_events within the current call
   std::vector<std::pair<hipEvent_t, hipEvent_t>> chain_ms_events;  // timing brackets of the chain launches of the last call
   // rnnoise.rs:114-164: the samples of a call that do not fill a 480-sample frame wait here for the next call
   float *d_pending = nullptr;   // [streams][480]
@@ -148,6 +153,20 @@ struct af_engine {
   int32_t *d_trace = nullptr;   // [frames][streams][2]: (silence, pitch index) of every frame of the last call
   int64_t trace_capacity = 0, trace_frames = 0;
   bool trace = false;
+  // the stage-pipeline form of the chain (af_stages.hip): rings, one stream and a ring of events per stage
+  struct StagePipe {
+    bool decided = false, active = false;  // chosen at the first call after a reset, then kept (the rings ARE the histories)
+    af::StageRings rings{};
+    std::vector<void *> allocs;
+    int64_t tw_max = 0;                    // longest window the rings were sized for
+    hipStream_t streams[af::kStCount] = {};
+    static constexpr int kEventRing = 32;
+    hipEvent_t done[af::kStCount][kEventRing] = {};
+    int64_t windows = 0;                   // windows launched since the rings were last cleared
+    static constexpr int kMkSets = 16;
+    double *d_mk = nullptr;
+    int64_t mk_rows = 0;                   // rows (blocks x streams) per set
+  } pipe;
   int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
@@ -601,6 +620,196 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   return AF_OK;
 }
 
+
+// an event of the engine's pool, valid until the end of the current process call
+int engine_event(af_engine *e, hipEvent_t *out_ev) {
+  if (e->ev_cursor == e->sync_events.size()) {
+    hipEvent_t ev;
+    AF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->sync_events.push_back(ev);
+  }
+  *out_ev = e->sync_events[e->ev_cursor++];
+  return AF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The stage-pipeline form of the chain (af_stages.hip).  Which configurations it serves:
+bool stage_pipe_serves(const af_engine *e, const af::ChainParams &run, int32_t layout) {
+  if (!e->extra_presets.empty() || layout != AF_LAYOUT_STREAM_MAJOR) return false;
+  if (run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
+  if ((run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled) return false;
+  if ((run.flags & af::kFlagEq) && run.n_eq_sections > 16) return false;
+  for (int k = 0; k < run.n_eq_sections; ++k)
+    if (run.eq[k].xf_remaining > 0) return false;
+  if ((run.flags & af::kFlagLimiter) && run.lim.lookahead_samples > af::kMaxLookahead) return false;
+  return true;
+}
+
+size_t pow2_at_least(int64_t n) {
+  size_t p = 1;
+  while ((int64_t)p < n) p <<= 1;
+  return p;
+}
+
+// rings sized for windows of up to `tw_max` samples, the streams and the events
+int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
+  auto &sp = e->pipe;
+  if (sp.rings.xe && tw_max <= sp.tw_max) return AF_OK;
+  if (sp.rings.xe) {  // grow: only between calls of a fresh engine (the rings hold the histories)
+    if (sp.windows > 0) return fail(AF_ERR_UNSUPPORTED, "a call of %lld samples per window after smaller ones: the stage pipeline's rings were sized for %lld",
+                                    (long long)tw_max, (long long)sp.tw_max);
+    AF_HIP(hipDeviceSynchronize());
+    for (void *p : sp.allocs) (void)hipFree(p);
+    sp.allocs.clear();
+    sp.rings = af::StageRings{};
+  }
+  const int64_t groups = (e->n_streams + 63) / 64;
+  const int64_t hist = 2 * (af::kMaxLookahead + 1) + 64;
+  const size_t r64 = pow2_at_least(5 * tw_max + hist), r32 = pow2_at_least(12 * tw_max + hist);
+  sp.rings.rows_f64 = (int32_t)r64;
+  sp.rings.rows_f32 = (int32_t)r32;
+  auto ring32 = [&](float **p) -> hipError_t {
+    hipError_t err = hipMalloc(p, sizeof(float) * r32 * 64 * groups);
+    if (err != hipSuccess) return err;
+    sp.allocs.push_back(*p);
+    return hipMemset(*p, 0, sizeof(float) * r32 * 64 * groups);
+  };
+  auto ring64 = [&](double **p) -> hipError_t {
+    hipError_t err = hipMalloc(p, sizeof(double) * r64 * 64 * groups);
+    if (err != hipSuccess) return err;
+    sp.allocs.push_back(*p);
+    return hipMemset(*p, 0, sizeof(double) * r64 * 64 * groups);
+  };
+  af::StageRings &r = sp.rings;
+  for (float **p : {&r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.od}) AF_HIP(ring32(p));
+  for (double **p : {&r.d, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.tg, &r.g})
+    AF_HIP(ring64(p));
+  sp.tw_max = tw_max;
+  const int cb = e->host_params.control_block;
+  sp.mk_rows = ((tw_max + cb - 1) / cb + 1) * e->n_streams;
+  if (sp.d_mk) (void)hipFree(sp.d_mk);
+  AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
+  for (int k = 0; k < af::kStCount; ++k) {
+    if (!sp.streams[k]) {
+      // the serial stages are what the pipeline waits for: their queues go first
+      const bool serial = k == af::kStCompA || k == af::kStCompC || k == af::kStCompE || k == af::kStLim || k == af::kStTp;
+      // a queue of its own per stage (streams created the plain way share a few hardware queues, and kernels of one
+      // queue run in order: the stages would not overlap): a CU-masked stream with every CU enabled
+      hipDeviceProp_t prop;
+      AF_HIP(hipGetDeviceProperties(&prop, e->device));
+      std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
+      for (int bit = 0; bit < prop.multiProcessorCount; ++bit) mask[bit >> 5] |= 1u << (bit & 31);
+      if (hipExtStreamCreateWithCUMask(&sp.streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        AF_HIP(hipStreamCreateWithPriority(&sp.streams[k], hipStreamNonBlocking, serial ? hi : lo));
+      }
+    }
+    for (int i = 0; i < af_engine::StagePipe::kEventRing; ++i)
+      if (!sp.done[k][i]) AF_HIP(hipEventCreateWithFlags(&sp.done[k][i], hipEventDisableTiming));
+  }
+  return AF_OK;
+}
+
+int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
+  auto &sp = e->pipe;
+  if (!sp.rings.xe) return AF_OK;
+  const int64_t groups = (e->n_streams + 63) / 64;
+  af::StageRings &r = sp.rings;
+  for (float *p : {r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
+  for (double *p : {r.d, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.tg, r.g})
+    AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+  sp.windows = 0;
+  return AF_OK;
+}
+
+// One window through the stage kernels.  `in_audio`: stream-major audio after the EQ (the systolic EQ kernel's output),
+// valid once `ready` has fired; `out` receives the chain output.  Every stage runs on its own stream: behind the previous
+// stage of this window, behind itself of the previous window (stream order), and behind the consumers of the ring rows it
+// is about to overwrite.
+int stage_pipe_window(af_engine *e, const af::ChainParams &run, const af::ChainParams *d_params, const float *in_audio, float *out,
+                      int64_t n, int64_t stride, int64_t n0_abs, af::BlockStats *stats, hipEvent_t ready) {
+  auto &sp = e->pipe;
+  const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
+  int order[af::kStCount], n_order = 0;
+  order[n_order++] = af::kStTin;
+  if (comp) for (int k : {af::kStCompA, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE, af::kStF3}) order[n_order++] = k;
+  if (lim) for (int k : {af::kStF4, af::kStLim, af::kStF5}) order[n_order++] = k;
+  order[n_order++] = af::kStTp;
+  order[n_order++] = af::kStF6;
+  // who reads last what a stage writes, and in which kind of ring
+  auto last_consumer = [&](int k, bool *f32) -> int {
+    *f32 = false;
+    switch (k) {
+      case af::kStTin: *f32 = true; return comp ? af::kStF3 : (lim ? af::kStF5 : af::kStTp);
+      case af::kStCompA: return af::kStF1;
+      case af::kStF1: return af::kStF2;
+      case af::kStCompC: return af::kStF2;
+      case af::kStF2: return af::kStCompE;
+      case af::kStCompE: return af::kStF3;
+      case af::kStF3: *f32 = true; return lim ? af::kStF5 : af::kStTp;
+      case af::kStF4: return af::kStLim;
+      case af::kStLim: return af::kStF5;
+      case af::kStF5: *f32 = true; return af::kStTp;
+      case af::kStTp: *f32 = true; return af::kStF6;
+      default: return -1;
+    }
+  };
+  const int64_t w = sp.windows;
+  const int slot = (int)(w % af_engine::StagePipe::kEventRing);
+  const int64_t d64 = std::min<int64_t>(sp.rings.rows_f64 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
+  const int64_t d32 = std::min<int64_t>(sp.rings.rows_f32 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
+  af::StageArgs a{};
+  a.params = d_params;
+  a.group_preset = nullptr;
+  a.st64 = e->d_st64;
+  a.st32 = e->d_st32;
+  a.stats = stats;
+  a.mk = sp.d_mk + (w % af_engine::StagePipe::kMkSets) * sp.mk_rows;
+  a.in = in_audio;
+  a.out = out;
+  a.stream_stride = stride;
+  a.n = n;
+  a.n0 = n0_abs;
+  a.n_streams = e->n_streams;
+  a.w_min = run.lim.lookahead_samples + 1;
+  a.r = sp.rings;
+  for (int i = 0; i < n_order; ++i) {
+    const int k = order[i];
+    const hipStream_t st = sp.streams[k];
+    if (i == 0) {
+      if (ready) AF_HIP(hipStreamWaitEvent(st, ready, 0));
+    } else {
+      AF_HIP(hipStreamWaitEvent(st, sp.done[order[i - 1]][slot], 0));
+    }
+    bool f32 = false;
+    const int consumer = last_consumer(k, &f32);
+    const int64_t depth = std::min<int64_t>(f32 ? d32 : d64, af_engine::StagePipe::kMkSets - 1);
+    if (consumer >= 0 && w - depth >= 0)
+      AF_HIP(hipStreamWaitEvent(st, sp.done[consumer][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
+    AF_HIP(af::launch_stage(k, a, run.flags, st));
+    AF_HIP(hipEventRecord(sp.done[k][slot], st));
+    e->last_launches += 1;
+  }
+  sp.windows += 1;
+  return AF_OK;
+}
+
+// the caller's stream waits for everything the pipeline has in flight
+int stage_pipe_join(af_engine *e, const af::ChainParams &run, hipStream_t stream) {
+  auto &sp = e->pipe;
+  if (sp.windows == 0) return AF_OK;
+  const int slot = (int)((sp.windows - 1) % af_engine::StagePipe::kEventRing);
+  const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
+  for (int k = 0; k < af::kStCount; ++k) {
+    const bool is_comp = k >= af::kStCompA && k <= af::kStF3, is_lim = k >= af::kStF4 && k <= af::kStF5;
+    if ((is_comp && !comp) || (is_lim && !lim)) continue;
+    AF_HIP(hipStreamWaitEvent(stream, sp.done[k][slot], 0));
+  }
+  return AF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -652,6 +861,17 @@ void af_engine_destroy(af_engine *e) {
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
   }
+  if (e->pipe.rings.xe || e->pipe.d_mk) {
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->pipe.allocs) (void)hipFree(p);
+    (void)hipFree(e->pipe.d_mk);
+  }
+  for (auto &row : e->pipe.done)
+    for (hipEvent_t ev : row)
+      if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : e->pipe.streams)
+    if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = nullptr;
@@ -675,6 +895,7 @@ int af_engine_reset(af_engine *e) {
     AF_HIP(hipDeviceSynchronize());
   }
   e->started = false;
+  e->pipe.decided = false;
   e->params_dirty = true;
   e->samples_processed = 0;
   e->last_blocks = 0;
@@ -880,7 +1101,7 @@ int af_engine_assign_presets(af_engine *e, const int32_t *preset_of_group, int32
 
 int af_engine_set_kernel(af_engine *e, int32_t kernel) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_QUAD) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_STAGED) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   e->kernel = kernel;
   return AF_OK;
 }
@@ -959,6 +1180,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
   e->last_output_samples = n_samples;
   e->trace_frames = 0;
+  e->ev_cursor = 0;
   const int cb = e->host_params.control_block;
   const int64_t blocks = (n_samples + cb - 1) / cb;
   e->last_blocks = blocks;
@@ -989,6 +1211,66 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   e->chain_ms_events.clear();
 
+  if (!e->pipe.decided) {  // first call after a reset: which form of the chain this engine runs
+    af::ChainParams probe = e->host_params;
+    if (e->supp.enabled) probe.flags &= ~(af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub);
+    const bool serves = stage_pipe_serves(e, probe, layout);
+    static const int env_staged = [] {  // AF_STAGED=0 / 1: keep AUTO off / on the stage pipeline (A/B runs)
+      const char *env = std::getenv("AF_STAGED");
+      return env ? std::atoi(env) : -1;
+    }();
+    if (e->kernel == AF_KERNEL_STAGED && !serves)
+      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, auto-makeup, front end without the "
+                                      "suppressor, more than 16 EQ sections, a pending EQ crossfade, several presets, time-major audio)");
+    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && kStagedByDefault) ||
+                                (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
+    e->pipe.decided = true;
+    if (e->pipe.active)
+      if (int rc = stage_pipe_clear(e)) return rc;
+  }
+  if (!e->supp.enabled && e->pipe.active) {
+    // ---- the chain as a pipeline of stage kernels over windows of whole control blocks (af_stages.hip)
+    const af::ChainParams &run = e->host_params;
+    int64_t tw = (int64_t)cb * std::max<int64_t>(1, 4800 / cb);
+    if (const char *env = std::getenv("AF_STAGE_WINDOW")) tw = (int64_t)cb * std::max<int64_t>(1, std::atoll(env) / cb);
+    if (int rc = stage_pipe_prepare(e, std::max<int64_t>(tw, e->pipe.tw_max))) return rc;
+    if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
+    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
+      e->uploaded = run;
+      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->uploaded_valid = true;
+    }
+    e->last_kernel_used = AF_KERNEL_STAGED;
+    hipEvent_t ev_in;
+    if (int rc = engine_event(e, &ev_in)) return rc;
+    AF_HIP(hipEventRecord(ev_in, stream));
+    const hipStream_t es = e->eq_stream;
+    AF_HIP(hipStreamWaitEvent(es, ev_in, 0));
+    int64_t blocks_done = 0;
+    for (int64_t t0 = 0; t0 < n_samples; t0 += tw) {
+      const int64_t n_w = std::min<int64_t>(tw, n_samples - t0);
+      af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
+      const int64_t blocks_w = (n_w + cb - 1) / cb;
+      AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * blocks_w * e->n_streams, es));
+      // input scrub / clamp, block input statistics, EQ: stream-major in -> stream-major out
+      AF_HIP(af::launch_eq_systolic(e->d_params, nullptr, e->d_st64, in + t0, out + t0, rows_w, n_w, stream_stride, e->n_streams, es));
+      e->last_launches += 1;
+      hipEvent_t ready;
+      if (int rc = engine_event(e, &ready)) return rc;
+      AF_HIP(hipEventRecord(ready, es));
+      if (int rc = stage_pipe_window(e, run, e->d_params, out + t0, out + t0, n_w, stream_stride, e->samples_processed + t0, rows_w, ready))
+        return rc;
+      blocks_done += blocks_w;
+    }
+    if (int rc = stage_pipe_join(e, run, stream)) return rc;
+    if (e->timing) {
+      AF_HIP(hipEventRecord(e->ev_mid, stream));
+      AF_HIP(hipEventRecord(e->ev_stop, stream));
+    }
+    e->samples_processed += n_samples;
+    return AF_OK;
+  }
   if (!e->supp.enabled) {
     int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
                                   e->d_stats, e->has_evidence ? e->d_vad : nullptr, stream, stream);
@@ -1128,7 +1410,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   const hipStream_t fin = split_synthesis ? e->fin_stream : nullptr;
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
   int64_t blocks_done = 0;
-  size_t ev_index = 0;
   static const bool eq_offload_env = [] {  // AF_EQ_OFFLOAD=0: the EQ stays inside the chain launches (A/B runs)
     const char *env = std::getenv("AF_EQ_OFFLOAD");
     return !env || std::atoi(env) != 0;
@@ -1136,15 +1417,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   const bool eq_offload = eq_offload_env && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) &&
                           (e->ring_variant == 0 || e->ring_variant == 1604) && (run.flags & af::kFlagEq);
   bool eq_needs_chain_done = true;  // (the previous call's last chain launch has ended: the caller's stream waited for it)
-  auto next_event = [&](hipEvent_t *out_ev) -> int {
-    if (ev_index == e->sync_events.size()) {
-      hipEvent_t ev;
-      AF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      e->sync_events.push_back(ev);
-    }
-    *out_ev = e->sync_events[ev_index++];
-    return AF_OK;
-  };
+  auto next_event = [&](hipEvent_t *out_ev) -> int { return engine_event(e, out_ev); };
   {  // the side streams start after whatever the caller queued before this call
     hipEvent_t ev;
     if (int rc = next_event(&ev)) return rc;
@@ -1286,7 +1559,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         }
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
         AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
-        AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, rows_w,
+        AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, rows_w,
                                       seg_n, stream_stride, e->n_streams, es));
         e->last_launches += 1;
         hipEvent_t eq_done;

@@ -30,7 +30,8 @@ struct EqSystolicArgs {
   const ChainParams *params;    // device; an array when `group_preset` is set
   const int32_t *group_preset;  // [ceil(n_streams / 64)] or null
   double *st64;                 // [f64 fields][n_streams]: the sections' memories (kEqBase + 4 sec + {0, 1})
-  float *audio;                 // [stream][stride], filtered in place
+  const float *in;              // [stream][stride]
+  float *audio;                 // [stream][stride]: the filtered samples (may be `in`: reads run three groups ahead of the stores)
   BlockStats *stats;            // [block][stream]: input_square_sum / input_sample_peak are written here
   int64_t n_samples, stream_stride;
   int32_t n_streams;
@@ -71,11 +72,12 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
   }
 
   float *row = a.audio + (int64_t)sc * a.stream_stride;
+  const float *row_in = a.in + (int64_t)sc * a.stream_stride;
   const int64_t n = a.n_samples;
   const int64_t groups = (n + 15) / 16;
   auto fetch = [&](int64_t g) -> float {
     const int64_t t = g * 16 + k;
-    float v = (g < groups && t < n) ? row[t] : 0.0f;
+    float v = (g < groups && t < n) ? row_in[t] : 0.0f;
     if (scrub && !finite_f32(v)) v = 0.0f;  // python_api.rs:515-523 / routing.rs:802-823 (every lane scrubs its own sample)
     if (clamp) v = fclamp(v, -1.0f, 1.0f);
     return v;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
   };
   for (int64_t g = 0; g < groups + 1; ++g) {
     const int left = __builtin_amdgcn_readfirstlane(cb - in_block);  // samples to the end of the control block
-    if (g < 1 || (g + 1) * 16 > n) group(g, std::true_type{}, std::true_type{});
+    if (g < 1 || (g + 1) * 16 >= n) group(g, std::true_type{}, std::true_type{});  // (>=: a short last block ends at T + 1 == n)
     else if (left <= 16) group(g, std::false_type{}, std::true_type{});
     else group(g, std::false_type{}, std::false_type{});
   }
@@ -205,9 +207,9 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
   }
 }
 
-hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, float *audio,
+hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               BlockStats *stats, int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream) {
-  EqSystolicArgs a{d_params, d_group_preset, st64, audio, stats, n_samples, stream_stride, n_streams};
+  EqSystolicArgs a{d_params, d_group_preset, st64, in, audio, stats, n_samples, stream_stride, n_streams};
   hipLaunchKernelGGL(eq_systolic_kernel, dim3((unsigned)((n_streams + 3) / 4)), dim3(64), 0, stream, a);
   return hipGetLastError();
 }

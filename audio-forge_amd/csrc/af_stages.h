@@ -1,0 +1,67 @@
+// af_stages.h -- arguments of the stage-pipeline form of the dynamics chain (af_stages.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "af_device.h"
+
+namespace af {
+
+// Hand-over buffers between the stage kernels.  Every one is a ring over ABSOLUTE sample index per 64-stream group,
+// time-major: element (group g, sample n, lane l) sits at ((g * rows + (n & (rows - 1))) * 64 + l); `rows` is a power of
+// two.  A row is one 256- or 512-byte line run, so a wave whose lane is the stream reads and writes whole rows.  History a
+// stage needs from before its window (limiter lookahead, the 32-tap true-peak windows, the 20-sample delay) is simply
+// older rows of the same ring, also across calls; a fresh engine starts from zeroed rings.
+struct StageRings {
+  float *xe;                                     // compressor input (after the EQ)
+  double *d, *low_e, *voiced_e, *pres_e, *rms_e; // side-chain signal and the four envelopes, per sample
+  double *ipk_db, *rms_db, *w_db;                // instantaneous peak / rms level, detector weight (dB)
+  double *peak_db;                               // log-domain peak envelope
+  double *target;                                // static gain-reduction target (dB)
+  double *gr;                                    // smoothed gain reduction (dB)
+  float *xc;                                     // limiter input (compressor output)
+  float *sfx;                                    // suffix maxima of |xc| inside lookahead-aligned blocks
+  double *tg;                                    // limiter target gain
+  double *g;                                     // limiter gain
+  float *xl;                                     // true-peak limiter input (limiter output)
+  float *itp, *tgt;                              // 4x true peak of xl and the target gain it asks for
+  float *od;                                     // chain output (time-major), input of the output-side detector
+  int32_t rows_f32, rows_f64;                    // ring lengths
+};
+
+struct StageArgs {
+  const ChainParams *params;    // device; an array when `group_preset` is set
+  const int32_t *group_preset;  // [groups] or null
+  double *st64;
+  float *st32;
+  BlockStats *stats;            // rows of this window: [block][stream]
+  double *mk;                   // [blocks of this window][stream]: linear makeup gain in force during the block
+  const float *in;              // stream-major audio at the two ends of the pipeline
+  float *out;
+  int64_t stream_stride;
+  int64_t n;                    // samples per stream in this window
+  int64_t n0;                   // absolute index of the window's first sample
+  int32_t n_streams;
+  int32_t w_min;                // smallest lookahead + 1 over the presets (sizes the limiter stage's grid)
+  StageRings r;
+};
+
+enum StageId : int {
+  kStTin = 0,  // stream-major -> time-major
+  kStCompA,    // serial: side-chain high-pass + band / rms envelopes
+  kStF1,       // levels in dB, detector weight
+  kStCompC,    // serial: log-domain peak envelope
+  kStF2,       // blended detector level -> gain-reduction target
+  kStCompE,    // serial: release meter + gain-reduction smoothing, makeup gain per block
+  kStF3,       // apply gain
+  kStF4,       // limiter: sliding maximum over the lookahead window -> target gain
+  kStLim,      // serial: limiter gain
+  kStF5,       // limiter output, input-side 4x true peak, true-peak target gain
+  kStTp,       // serial: true-peak gain, chain output, block output statistics
+  kStF6,       // output-side 4x true peak, time-major -> stream-major
+  kStCount
+};
+
+hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, hipStream_t stream);
+
+}  // namespace af

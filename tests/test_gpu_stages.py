@@ -1,0 +1,131 @@
+"""The stage-pipeline form of the chain (audio-forge_amd/csrc/af_stages.hip, AF_KERNEL_STAGED) against the token-ring
+kernel (AF_KERNEL_PHASED): the same expressions, operation for operation, in a build that does not contract
+floating-point expressions, so audio and block rows must agree BIT FOR BIT -- whatever the oracle tolerances of the
+libm-carrying stages are.  The oracle comparisons proper run in tests/test_gpu_parity.py (variant "staged")."""
+import numpy as np
+import pytest
+
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+TYPED_BANDS = [("bell", 80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0, 12, True) for i in range(10)]
+
+
+@pytest.fixture(scope="module")
+def core():
+    import mic_eq_mi
+    from mic_eq_mi import _lib, mic_eq_core
+
+    assert mic_eq_mi.CORE_AVAILABLE, "HIP library missing: GPU tests never fall back to the CPU"
+    assert _lib.load().af_device_count() >= 1
+    return mic_eq_core
+
+
+def run(core, kernel, audio, settings, calls, bands=TYPED_BANDS, fs=48_000.0):
+    eng = core.Engine(fs, audio.shape[0])
+    try:
+        settings = dict(settings)
+        settings["eq_bands_v2"] = bands  # typed bands: no coefficient crossfade opens the stream
+        core.configure_auto_eq_chain(eng, fs, S.LIMITER_BANDS, settings)
+        eng.set_kernel(kernel)
+        ys, rows = [], []
+        for lo, hi in calls:
+            ys.append(eng.process(audio[:, lo:hi]))
+            rows.append(eng.block_stats().copy())
+        assert eng._lib.af_engine_last_kernel(eng._h) == kernel
+        return np.concatenate(ys, axis=1), np.concatenate(rows, axis=0)
+    finally:
+        eng.close()
+
+
+def assert_same(a, b):
+    ya, ra = a
+    yb, rb = b
+    assert ya.shape == yb.shape
+    diff = np.flatnonzero(ya.view(np.uint32) != yb.view(np.uint32))
+    assert diff.size == 0, f"{diff.size} samples differ, first at {np.unravel_index(diff[0], ya.shape) if ya.ndim > 1 else diff[0]}"
+    for name in ra.dtype.names:
+        assert np.array_equal(ra[name], rb[name]), name
+
+
+CASES = {
+    "full dynamics": {},
+    "no side-chain filter": {"compressor_sidechain_highpass_enabled": False},
+    "fixed release": {"compressor_adaptive_release": False},
+    "compressor only": {"limiter_enabled": False},
+    "limiter only": {"compressor_enabled": False},
+    "neither": {"compressor_enabled": False, "limiter_enabled": False},
+    "short lookahead": {"limiter_lookahead_ms": 0.5},
+    "long lookahead": {"limiter_lookahead_ms": 5.0},
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_stage_pipeline_equals_token_ring(core, case):
+    """70 streams (a full group and a ragged one), 2.1 s in three calls of unequal, partly ragged length: windows of ten
+    control blocks, a short last window, a short last block, state and ring histories carried across calls."""
+    from mic_eq_mi import _lib
+
+    settings = dict(S.limiter_settings(2.0))
+    settings.update(CASES[case])
+    if case == "long lookahead":
+        # 240 samples of lookahead do not fit the token ring's LDS layout: the 16-stream kernel is the yardstick
+        ref_kernel = _lib.KERNEL_QUAD
+    else:
+        ref_kernel = _lib.KERNEL_PHASED
+    audio = S.batch_signal(70, 210) * np.float32(1.6)  # loud enough for the limiter and the true-peak stage to act
+    n = audio.shape[1]
+    calls = ((0, 31_007), (31_007, 31_007 + 480 * 77), (31_007 + 480 * 77, n))
+    want = run(core, ref_kernel, audio, settings, calls)
+    got = run(core, _lib.KERNEL_STAGED, audio, settings, calls)
+    assert_same(got, want)
+
+
+def test_tiny_calls(core):
+    """Calls shorter than a control block, shorter than the FIR history, and of one sample."""
+    from mic_eq_mi import _lib
+
+    settings = dict(S.limiter_settings(2.0))
+    audio = S.batch_signal(5, 12) * np.float32(1.5)
+    edges = [0, 1, 2, 33, 100, 479, 480, 481, 1500, 1501, 4000, audio.shape[1]]
+    calls = list(zip(edges[:-1], edges[1:]))
+    want = run(core, _lib.KERNEL_PHASED, audio, settings, calls)
+    got = run(core, _lib.KERNEL_STAGED, audio, settings, calls)
+    assert_same(got, want)
+
+
+def test_non_finite_input_and_scrub(core):
+    """NaN / Inf samples: the scrub in front, the limiter's and the detector's own scrubs, the non-finite flag."""
+    from mic_eq_mi import _lib
+
+    settings = dict(S.limiter_settings(2.0))
+    audio = S.batch_signal(3, 20).copy()
+    audio[0, 1000] = np.nan
+    audio[1, 2000:2004] = np.inf
+    audio[2, 3000] = -np.inf
+    for extra in ({}, {"compressor_enabled": False, "limiter_enabled": False}):
+        s = dict(settings)
+        s.update(extra)
+        calls = ((0, audio.shape[1]),)
+        want = run(core, _lib.KERNEL_PHASED, audio, s, calls)
+        got = run(core, _lib.KERNEL_STAGED, audio, s, calls)
+        ya, yb = got[0], want[0]
+        assert np.array_equal(np.isnan(ya), np.isnan(yb))
+        assert_same((np.nan_to_num(ya, nan=7.0), got[1]), (np.nan_to_num(yb, nan=7.0), want[1]))
+
+
+def test_unsupported_configurations_are_refused(core):
+    from mic_eq_mi import _lib
+
+    eng = core.Engine(48_000.0, 2)
+    try:
+        settings = dict(S.limiter_settings(2.0))
+        settings["eq_bands_v2"] = TYPED_BANDS
+        core.configure_auto_eq_chain(eng, 48_000.0, S.LIMITER_BANDS, settings)
+        eng.set_deesser_enabled(1)
+        eng.set_kernel(_lib.KERNEL_STAGED)
+        with pytest.raises(NotImplementedError, match="stage pipeline"):
+            eng.process(S.batch_signal(2, 2))
+    finally:
+        eng.close()
