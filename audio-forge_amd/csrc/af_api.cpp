@@ -41,12 +41,16 @@ hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32
                           BlockStats *rows, int64_t n_samples, int64_t stream_stride, int32_t n_streams,
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
 hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
-                              BlockStats *stats, int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream);
+                              float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
+                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
-// AUTO routes the configurations the stage pipeline serves to it
-constexpr bool kStagedByDefault = false;
+// AUTO routes the configurations the stage pipeline serves to it up to this many streams.  Measured (dynamics chain, 10 s,
+// one MI355X): 256 streams 50 ms against the token ring's 202, 1024 streams 84 against 202, 4096 streams 175 against 202;
+// beyond that the token ring wins (a launch of it lasts ~202 ms up to 16 384 streams) and the pipeline's rings (0.3 KB per
+// sample step per stream in flight) would take tens of GB.
+constexpr int kStagedAutoMaxStreams = 2048;
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
 static_assert(sizeof(af_block_stats) == 72, "stats row size");
@@ -639,8 +643,6 @@ bool stage_pipe_serves(const af_engine *e, const af::ChainParams &run, int32_t l
   if (run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
   if ((run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled) return false;
   if ((run.flags & af::kFlagEq) && run.n_eq_sections > 16) return false;
-  for (int k = 0; k < run.n_eq_sections; ++k)
-    if (run.eq[k].xf_remaining > 0) return false;
   if ((run.flags & af::kFlagLimiter) && run.lim.lookahead_samples > af::kMaxLookahead) return false;
   return true;
 }
@@ -649,6 +651,18 @@ size_t pow2_at_least(int64_t n) {
   size_t p = 1;
   while ((int64_t)p < n) p <<= 1;
   return p;
+}
+
+// A feed-forward stage shares the stream of the serial stage it feeds (it has to finish before that one starts anyway):
+// ten queues instead of fifteen, and an event less per pair.
+int stage_stream(int k) {
+  switch (k) {
+    case af::kStF1: return af::kStCompC;
+    case af::kStF2: return af::kStCompE;
+    case af::kStF3: case af::kStF4: return af::kStLim;
+    case af::kStF5: return af::kStTp;
+    default: return k;
+  }
 }
 
 // rings sized for windows of up to `tw_max` samples, the streams and the events
@@ -681,8 +695,8 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
     return hipMemset(*p, 0, sizeof(double) * r64 * 64 * groups);
   };
   af::StageRings &r = sp.rings;
-  for (float **p : {&r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.od}) AF_HIP(ring32(p));
-  for (double **p : {&r.d, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.tg, &r.g})
+  for (float **p : {&r.xi, &r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.gt, &r.od}) AF_HIP(ring32(p));
+  for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.tg, &r.g})
     AF_HIP(ring64(p));
   sp.tw_max = tw_max;
   const int cb = e->host_params.control_block;
@@ -690,16 +704,17 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   if (sp.d_mk) (void)hipFree(sp.d_mk);
   AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
   for (int k = 0; k < af::kStCount; ++k) {
-    if (!sp.streams[k]) {
+    if (!sp.streams[k] && stage_stream(k) == k) {
       // the serial stages are what the pipeline waits for: their queues go first
-      const bool serial = k == af::kStCompA || k == af::kStCompC || k == af::kStCompE || k == af::kStLim || k == af::kStTp;
+      const bool serial = k == af::kStEq || k == af::kStCompA || k == af::kStCompA2 || k == af::kStOut || k == af::kStCompC || k == af::kStCompE || k == af::kStLim || k == af::kStTp;
       // a queue of its own per stage (streams created the plain way share a few hardware queues, and kernels of one
       // queue run in order: the stages would not overlap): a CU-masked stream with every CU enabled
       hipDeviceProp_t prop;
       AF_HIP(hipGetDeviceProperties(&prop, e->device));
       std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
       for (int bit = 0; bit < prop.multiProcessorCount; ++bit) mask[bit >> 5] |= 1u << (bit & 31);
-      if (hipExtStreamCreateWithCUMask(&sp.streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      static const bool plain_streams = std::getenv("AF_STAGE_PLAIN_STREAMS") != nullptr;  // timing experiments
+      if (plain_streams || hipExtStreamCreateWithCUMask(&sp.streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -717,42 +732,53 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   if (!sp.rings.xe) return AF_OK;
   const int64_t groups = (e->n_streams + 63) / 64;
   af::StageRings &r = sp.rings;
-  for (float *p : {r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
-  for (double *p : {r.d, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.tg, r.g})
+  for (float *p : {r.xi, r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.gt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
+  for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.tg, r.g})
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
   sp.windows = 0;
   return AF_OK;
 }
 
-// One window through the stage kernels.  `in_audio`: stream-major audio after the EQ (the systolic EQ kernel's output),
-// valid once `ready` has fired; `out` receives the chain output.  Every stage runs on its own stream: behind the previous
-// stage of this window, behind itself of the previous window (stream order), and behind the consumers of the ring rows it
-// is about to overwrite.
-int stage_pipe_window(af_engine *e, const af::ChainParams &run, const af::ChainParams *d_params, const float *in_audio, float *out,
-                      int64_t n, int64_t stride, int64_t n0_abs, af::BlockStats *stats, hipEvent_t ready) {
+// One window through the stage kernels.  `in_audio`: the window's stream-major input, valid once `ready` has fired; `out`
+// receives the chain output (it may be `in_audio`: the EQ stage has read a window before its last stage writes it).
+// Every stage runs on its own stream: behind the stage it reads from (this window), behind itself of the previous window
+// (stream order), and behind the consumers of the ring rows it is about to overwrite.
+int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_audio, float *out, int64_t n, int64_t stride,
+                      int64_t n0_abs, af::BlockStats *stats, hipEvent_t ready) {
   auto &sp = e->pipe;
   const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
-  int order[af::kStCount], n_order = 0;
-  order[n_order++] = af::kStTin;
-  if (comp) for (int k : {af::kStCompA, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE, af::kStF3}) order[n_order++] = k;
-  if (lim) for (int k : {af::kStF4, af::kStLim, af::kStF5}) order[n_order++] = k;
-  order[n_order++] = af::kStTp;
-  order[n_order++] = af::kStF6;
+  // the stage list of this configuration, each with the stage it reads from
+  int order[af::kStCount], pred[af::kStCount], n_order = 0;
+  auto add = [&](int k, int from) { order[n_order] = k; pred[n_order] = from; ++n_order; };
+  add(af::kStEq, -1);
+  add(af::kStIn, af::kStEq);
+  int last = af::kStEq;
+  if (comp) {
+    for (int k : {af::kStCompA, af::kStCompA2, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE, af::kStF3}) { add(k, last); last = k; }
+  }
+  if (lim) {
+    for (int k : {af::kStF4, af::kStLim, af::kStF5}) { add(k, last); last = k; }
+  }
+  if (lim) { add(af::kStTp, last); last = af::kStTp; }
+  add(af::kStOut, last);
+  add(af::kStF6, af::kStOut);
   // who reads last what a stage writes, and in which kind of ring
   auto last_consumer = [&](int k, bool *f32) -> int {
     *f32 = false;
     switch (k) {
-      case af::kStTin: *f32 = true; return comp ? af::kStF3 : (lim ? af::kStF5 : af::kStTp);
+      case af::kStEq: *f32 = true; return comp ? af::kStF3 : (lim ? af::kStF5 : af::kStOut);  // xe (xi: the input statistics, sooner)
       case af::kStCompA: return af::kStF1;
+      case af::kStCompA2: return af::kStF1;
       case af::kStF1: return af::kStF2;
       case af::kStCompC: return af::kStF2;
       case af::kStF2: return af::kStCompE;
       case af::kStCompE: return af::kStF3;
-      case af::kStF3: *f32 = true; return lim ? af::kStF5 : af::kStTp;
+      case af::kStF3: *f32 = true; return lim ? af::kStF5 : af::kStOut;
       case af::kStF4: return af::kStLim;
       case af::kStLim: return af::kStF5;
-      case af::kStF5: *f32 = true; return af::kStTp;
-      case af::kStTp: *f32 = true; return af::kStF6;
+      case af::kStF5: *f32 = true; return af::kStOut;
+      case af::kStTp: *f32 = true; return af::kStOut;
+      case af::kStOut: *f32 = true; return af::kStF6;
       default: return -1;
     }
   };
@@ -761,7 +787,7 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const af::ChainP
   const int64_t d64 = std::min<int64_t>(sp.rings.rows_f64 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
   const int64_t d32 = std::min<int64_t>(sp.rings.rows_f32 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
   af::StageArgs a{};
-  a.params = d_params;
+  a.params = e->d_params;
   a.group_preset = nullptr;
   a.st64 = e->d_st64;
   a.st32 = e->d_st32;
@@ -777,18 +803,40 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const af::ChainP
   a.r = sp.rings;
   for (int i = 0; i < n_order; ++i) {
     const int k = order[i];
-    const hipStream_t st = sp.streams[k];
-    if (i == 0) {
+    const hipStream_t st = sp.streams[stage_stream(k)];
+    if (pred[i] < 0) {
       if (ready) AF_HIP(hipStreamWaitEvent(st, ready, 0));
-    } else {
-      AF_HIP(hipStreamWaitEvent(st, sp.done[order[i - 1]][slot], 0));
+    } else if (stage_stream(pred[i]) != stage_stream(k)) {
+      AF_HIP(hipStreamWaitEvent(st, sp.done[pred[i]][slot], 0));
     }
     bool f32 = false;
     const int consumer = last_consumer(k, &f32);
     const int64_t depth = std::min<int64_t>(f32 ? d32 : d64, af_engine::StagePipe::kMkSets - 1);
-    if (consumer >= 0 && w - depth >= 0)
+    static const bool no_gate = std::getenv("AF_STAGE_NOGATE") != nullptr;  // timing experiments only (unsafe)
+    if (!no_gate && consumer >= 0 && w - depth >= 0)
       AF_HIP(hipStreamWaitEvent(st, sp.done[consumer][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
-    AF_HIP(af::launch_stage(k, a, run.flags, st));
+    if (k == af::kStEq) {
+      // the section parameters this window's EQ reads (a coefficient crossfade moves them from window to window): uploaded
+      // in stream order, behind the previous window's EQ launch
+      bool crossfade = false;
+      for (int j = 0; j < run.n_eq_sections; ++j) crossfade |= run.eq[j].xf_remaining > 0;
+      if (!e->d_params_eq || e->eq_params_presets != 1) {
+        if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
+        e->d_params_eq = nullptr;
+        AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams)));
+        e->eq_params_presets = 1;
+        e->uploaded_eq.clear();
+      }
+      if (e->uploaded_eq.size() != 1 || std::memcmp(e->uploaded_eq.data(), &run, sizeof run) != 0) {
+        e->uploaded_eq.assign(1, run);
+        AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, st));
+        AF_HIP(hipStreamSynchronize(st));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
+      }
+      AF_HIP(af::launch_eq_systolic(e->d_params_eq, nullptr, e->d_st64, in_audio, nullptr, sp.rings.xe, sp.rings.xi, sp.rings.rows_f32, n0_abs,
+                                    nullptr, crossfade, n, stride, e->n_streams, st));
+    } else {
+      AF_HIP(af::launch_stage(k, a, run.flags, run.comp, st));
+    }
     AF_HIP(hipEventRecord(sp.done[k][slot], st));
     e->last_launches += 1;
   }
@@ -803,8 +851,8 @@ int stage_pipe_join(af_engine *e, const af::ChainParams &run, hipStream_t stream
   const int slot = (int)((sp.windows - 1) % af_engine::StagePipe::kEventRing);
   const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
   for (int k = 0; k < af::kStCount; ++k) {
-    const bool is_comp = k >= af::kStCompA && k <= af::kStF3, is_lim = k >= af::kStF4 && k <= af::kStF5;
-    if ((is_comp && !comp) || (is_lim && !lim)) continue;
+    const bool is_comp = k >= af::kStCompA && k <= af::kStF3, is_lim = k >= af::kStF4 && k <= af::kStTp;
+    if ((is_comp && !comp) || (is_lim && !lim)) continue;  // (the EQ, input-statistics, output and detector stages always run)
     AF_HIP(hipStreamWaitEvent(stream, sp.done[k][slot], 0));
   }
   return AF_OK;
@@ -1221,8 +1269,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }();
     if (e->kernel == AF_KERNEL_STAGED && !serves)
       return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, auto-makeup, front end without the "
-                                      "suppressor, more than 16 EQ sections, a pending EQ crossfade, several presets, time-major audio)");
-    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && kStagedByDefault) ||
+                                      "suppressor, more than 16 EQ sections, several presets, time-major audio)");
+    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
     if (e->pipe.active)
@@ -1230,40 +1278,40 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   }
   if (!e->supp.enabled && e->pipe.active) {
     // ---- the chain as a pipeline of stage kernels over windows of whole control blocks (af_stages.hip)
-    const af::ChainParams &run = e->host_params;
-    int64_t tw = (int64_t)cb * std::max<int64_t>(1, 4800 / cb);
+    // windows of ~0.2 s: with 4800-sample windows the queues' hand-overs cost as much as the kernels (59 ms per 10 s at 256
+    // streams), with 9600 49 ms, with 19200 the pipeline's fill time takes the gain back (49 ms)
+    int64_t tw = (int64_t)cb * std::max<int64_t>(1, (e->n_streams <= 1024 ? 9600 : 4800) / cb);
     if (const char *env = std::getenv("AF_STAGE_WINDOW")) tw = (int64_t)cb * std::max<int64_t>(1, std::atoll(env) / cb);
     if (int rc = stage_pipe_prepare(e, std::max<int64_t>(tw, e->pipe.tw_max))) return rc;
-    if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
-    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
-      e->uploaded = run;
-      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      e->uploaded_valid = true;
+    {
+      const af::ChainParams &run = e->host_params;  // what the stage kernels read (everything but the EQ sections)
+      if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
+        e->uploaded = run;
+        AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
+        AF_HIP(hipStreamSynchronize(stream));
+        e->uploaded_valid = true;
+      }
     }
     e->last_kernel_used = AF_KERNEL_STAGED;
     hipEvent_t ev_in;
     if (int rc = engine_event(e, &ev_in)) return rc;
     AF_HIP(hipEventRecord(ev_in, stream));
-    const hipStream_t es = e->eq_stream;
-    AF_HIP(hipStreamWaitEvent(es, ev_in, 0));
     int64_t blocks_done = 0;
     for (int64_t t0 = 0; t0 < n_samples; t0 += tw) {
       const int64_t n_w = std::min<int64_t>(tw, n_samples - t0);
       af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
       const int64_t blocks_w = (n_w + cb - 1) / cb;
-      AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * blocks_w * e->n_streams, es));
-      // input scrub / clamp, block input statistics, EQ: stream-major in -> stream-major out
-      AF_HIP(af::launch_eq_systolic(e->d_params, nullptr, e->d_st64, in + t0, out + t0, rows_w, n_w, stream_stride, e->n_streams, es));
-      e->last_launches += 1;
-      hipEvent_t ready;
-      if (int rc = engine_event(e, &ready)) return rc;
-      AF_HIP(hipEventRecord(ready, es));
-      if (int rc = stage_pipe_window(e, run, e->d_params, out + t0, out + t0, n_w, stream_stride, e->samples_processed + t0, rows_w, ready))
+      // (the call's rows are cleared on the EQ stage's stream, ahead of every stage that writes into them)
+      if (t0 == 0) {
+        AF_HIP(hipStreamWaitEvent(e->pipe.streams[af::kStEq], ev_in, 0));
+        AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, e->pipe.streams[af::kStEq]));
+      }
+      if (int rc = stage_pipe_window(e, e->host_params, in + t0, out + t0, n_w, stream_stride, e->samples_processed + t0, rows_w, nullptr))
         return rc;
+      advance_crossfades(e, n_w);
       blocks_done += blocks_w;
     }
-    if (int rc = stage_pipe_join(e, run, stream)) return rc;
+    if (int rc = stage_pipe_join(e, e->host_params, stream)) return rc;
     if (e->timing) {
       AF_HIP(hipEventRecord(e->ev_mid, stream));
       AF_HIP(hipEventRecord(e->ev_stop, stream));
@@ -1559,8 +1607,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         }
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
         AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
-        AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, rows_w,
-                                      seg_n, stream_stride, e->n_streams, es));
+        AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
+                                      rows_w, false, seg_n, stream_stride, e->n_streams, es));
         e->last_launches += 1;
         hipEvent_t eq_done;
         if (int rc2 = next_event(&eq_done)) return rc2;

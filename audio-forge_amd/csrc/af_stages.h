@@ -7,14 +7,17 @@
 
 namespace af {
 
-// Hand-over buffers between the stage kernels.  Every one is a ring over ABSOLUTE sample index per 64-stream group,
-// time-major: element (group g, sample n, lane l) sits at ((g * rows + (n & (rows - 1))) * 64 + l); `rows` is a power of
-// two.  A row is one 256- or 512-byte line run, so a wave whose lane is the stream reads and writes whole rows.  History a
+// Hand-over buffers between the stage kernels.  Every one is a ring over ABSOLUTE sample index per 64-stream group, `rows`
+// samples long (a power of two), time-major in quads: element (group g, sample n, lane l) sits at
+// g * rows * 64 + ((n >> 2) mod (rows / 4)) * 256 + l * 4 + (n & 3), i.e. a lane's four consecutive samples are one
+// 16- or 32-byte run and a wave whose lane is the stream moves four steps with one vector load or store.  History a
 // stage needs from before its window (limiter lookahead, the 32-tap true-peak windows, the 20-sample delay) is simply
 // older rows of the same ring, also across calls; a fresh engine starts from zeroed rings.
 struct StageRings {
+  float *xi;                                     // chain input after scrub / clamp (what the block input statistics see)
   float *xe;                                     // compressor input (after the EQ)
-  double *d, *low_e, *voiced_e, *pres_e, *rms_e; // side-chain signal and the four envelopes, per sample
+  double *d, *pr;                                // side-chain signal, its presence-weighted form
+  double *low_e, *voiced_e, *pres_e, *rms_e;     // the four envelopes, per sample
   double *ipk_db, *rms_db, *w_db;                // instantaneous peak / rms level, detector weight (dB)
   double *peak_db;                               // log-domain peak envelope
   double *target;                                // static gain-reduction target (dB)
@@ -25,6 +28,7 @@ struct StageRings {
   double *g;                                     // limiter gain
   float *xl;                                     // true-peak limiter input (limiter output)
   float *itp, *tgt;                              // 4x true peak of xl and the target gain it asks for
+  float *gt;                                     // true-peak limiter gain
   float *od;                                     // chain output (time-major), input of the output-side detector
   int32_t rows_f32, rows_f64;                    // ring lengths
 };
@@ -36,7 +40,7 @@ struct StageArgs {
   float *st32;
   BlockStats *stats;            // rows of this window: [block][stream]
   double *mk;                   // [blocks of this window][stream]: linear makeup gain in force during the block
-  const float *in;              // stream-major audio at the two ends of the pipeline
+  const float *in;              // stream-major audio at the two ends of the pipeline (`in`: read by the EQ stage only)
   float *out;
   int64_t stream_stride;
   int64_t n;                    // samples per stream in this window
@@ -47,8 +51,10 @@ struct StageArgs {
 };
 
 enum StageId : int {
-  kStTin = 0,  // stream-major -> time-major
-  kStCompA,    // serial: side-chain high-pass + band / rms envelopes
+  kStEq = 0,   // scrub / clamp + 10-band EQ (af_eq_systolic.hip): stream-major audio -> the xi and xe rings
+  kStIn,       // serial: block input statistics
+  kStCompA,    // serial: side-chain high-pass, low-band envelope, presence signal
+  kStCompA2,   // serial: voiced / presence / rms envelopes
   kStF1,       // levels in dB, detector weight
   kStCompC,    // serial: log-domain peak envelope
   kStF2,       // blended detector level -> gain-reduction target
@@ -57,11 +63,13 @@ enum StageId : int {
   kStF4,       // limiter: sliding maximum over the lookahead window -> target gain
   kStLim,      // serial: limiter gain
   kStF5,       // limiter output, input-side 4x true peak, true-peak target gain
-  kStTp,       // serial: true-peak gain, chain output, block output statistics
+  kStTp,       // serial: true-peak gain
+  kStOut,      // serial: chain output, block output statistics
   kStF6,       // output-side 4x true peak, time-major -> stream-major
   kStCount
 };
 
-hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, hipStream_t stream);
+// `flags`, `cp`: the chain flags and compressor switches the pipeline was planned for (they pick kernel variants)
+hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream);
 
 }  // namespace af

@@ -9,15 +9,22 @@
 // recurrence in its loop -- and every feed-forward piece is a wide elementwise kernel over (sample, stream).  The kernels
 // of a window run back to back on streams of their own, so while stage k works on window w stage k+1 works on window
 // w-1: a launch set lasts as long as the SLOWEST STAGE needs per sample, not the sum, and the feed-forward work spreads
-// over the whole chip.  Hand-over between stages is through time-major rings in HBM (af_stages.h): at 4096 streams that
-// is ~0.2 KB per sample step per stream of extra traffic, two orders of magnitude under the HBM roof for this work.
+// over the whole chip.  Hand-over between stages is through rings in HBM (af_stages.h), ~0.3 KB per sample step per
+// stream: nothing at a few hundred streams, the reason large batches stay on the token-ring kernel.
+//
+// What bounds a serial stage (tools/probe/valu_latency.hip): a lone wave issues a dependent vector instruction every
+// ~8.3 cycles and an independent one every ~5, whatever its type, and may have 63 memory instructions in flight.  So a
+// stage's loop holds nothing but its recurrence, and a lane's four consecutive samples are contiguous in the rings: one
+// 16-byte load or store moves four steps (a quarter of the memory instructions of a row-per-step layout).
 //
 // Arithmetic: the expressions are those of the token-ring kernel, operation for operation (the build does not contract
 // floating-point expressions), so the two kernels agree bit for bit; tests/test_gpu_stages.py holds them to that.
 //
-// Not built in this form (the host keeps such configurations on kernel 2): the de-esser's EQ-first order, auto-makeup,
-// a pending EQ crossfade, the time-major boundary layout.
+// Not built in this form (the host keeps such configurations on kernel 2): the de-esser, auto-makeup, the front end
+// without the suppressor, more than 16 EQ sections, several presets, the time-major boundary layout.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "af_dsp.h"
 #include "af_stages.h"
@@ -25,10 +32,34 @@
 namespace af {
 namespace {
 
-constexpr int kU = 16;        // steps per unrolled block of a serial stage
-constexpr int kTileRows = 64; // rows per workgroup of a feed-forward stage (4 waves x 16 rows)
+constexpr int kQ = 4;          // steps per quad: a lane's kQ consecutive samples are contiguous in every ring
+constexpr int kU = 16;         // steps per unrolled block of a serial stage (kU / kQ quads)
+constexpr int kTileRows = 64;  // steps per workgroup of a tiled feed-forward stage (4 waves x 16 steps)
+constexpr int kQuadRow = kLanes * kQ;
 
-__device__ __forceinline__ int64_t rrow(int64_t n, int rows) { return (n & (int64_t)(rows - 1)) * kLanes; }
+// ring addressing: element (sample n, lane l) of a group = quad (n >> 2) [modulo the ring], then lane, then n & 3
+__device__ __forceinline__ int64_t qoff(int64_t q, int rows) { return (q & (int64_t)(rows / kQ - 1)) * kQuadRow; }
+__device__ __forceinline__ int64_t eoff(int64_t n, int lane, int rows) { return qoff(n >> 2, rows) + lane * kQ + (n & 3); }
+
+template <typename T>
+struct Quad {
+  T v[kQ];
+};
+__device__ __forceinline__ Quad<float> load_quad(const float *p) {
+  const float4 x = *reinterpret_cast<const float4 *>(p);
+  return Quad<float>{{x.x, x.y, x.z, x.w}};
+}
+__device__ __forceinline__ Quad<double> load_quad(const double *p) {
+  const double2 a = *reinterpret_cast<const double2 *>(p), b = *reinterpret_cast<const double2 *>(p + 2);
+  return Quad<double>{{a.x, a.y, b.x, b.y}};
+}
+__device__ __forceinline__ void store_quad(float *p, const float (&v)[kU], int k) {
+  *reinterpret_cast<float4 *>(p) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+__device__ __forceinline__ void store_quad(double *p, const double (&v)[kU], int k) {
+  *reinterpret_cast<double2 *>(p) = make_double2(v[4 * k], v[4 * k + 1]);
+  *reinterpret_cast<double2 *>(p + 2) = make_double2(v[4 * k + 2], v[4 * k + 3]);
+}
 
 // what every stage works out first
 struct Who {
@@ -50,145 +81,299 @@ __device__ __forceinline__ const ChainParams &preset(const StageArgs &a, int g) 
   return a.params[a.group_preset ? a.group_preset[g] : 0];
 }
 
-// input of a serial stage: three blocks of kU rows in registers, the loads of block i + 3 issued when block i starts
+// Input of a serial stage: three blocks of kU steps (four quads each) in registers; the loads of block i + 3 are issued
+// when block i is done, into the buffer block i has just left (the loop is written out three times, so the buffers rotate
+// by name: a rotation by copying costs four register moves per step, a third of a lean stage's instructions).  Slot u of
+// a block is absolute sample 4 * qb + u (qb = the block's first quad).
 template <typename T>
 struct Ahead {
-  T cur[kU], n1[kU], n2[kU];
-  const T *base;  // ring of this group, at this lane
-  int rows;
-  int64_t n0;
-  __device__ __forceinline__ void fill(T (&v)[kU], int64_t t) {
+  T b0[kU], b1[kU], b2[kU];
+  const T *base;  // ring of this group
+  int rows, lane;
+  int64_t shift;  // in quads: read sample n + 4 * shift where the stage is at sample n (a delay line)
+  __device__ __forceinline__ void fill(T (&v)[kU], int64_t qb) {
 #pragma unroll
-    for (int u = 0; u < kU; ++u) v[u] = base[rrow(n0 + t + u, rows)];
-  }
-  __device__ __forceinline__ void init(const T *ring, int g, int lane, int rows_, int64_t n0_, int64_t shift = 0) {
-    base = ring + (int64_t)g * rows_ * kLanes + lane;
-    rows = rows_;
-    n0 = n0_ + shift;
-    fill(cur, 0);
-    fill(n1, kU);
-    fill(n2, 2 * kU);
-  }
-  __device__ __forceinline__ void advance(int64_t t) {
+    for (int k = 0; k < kU / kQ; ++k) {
+      const Quad<T> x = load_quad(base + qoff(qb + shift + k, rows) + lane * kQ);
 #pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      cur[u] = n1[u];
-      n1[u] = n2[u];
+      for (int j = 0; j < kQ; ++j) v[kQ * k + j] = x.v[j];
     }
-    fill(n2, t + 3 * kU);
+  }
+  __device__ __forceinline__ void init(const T *ring, int g, int lane_, int rows_, int64_t qb, int64_t shift_ = 0) {
+    base = ring + (int64_t)g * rows_ * kLanes;
+    rows = rows_;
+    lane = lane_;
+    shift = shift_;
+    fill(b0, qb);
+    fill(b1, qb + kU / kQ);
+    fill(b2, qb + 2 * (kU / kQ));
+  }
+  template <int I>
+  __device__ __forceinline__ T (&buf())[kU] {
+    if constexpr (I == 0) return b0;
+    else if constexpr (I == 1) return b1;
+    else return b2;
+  }
+  template <int I>
+  __device__ __forceinline__ void refill(int64_t qb) {  // qb: the block buffer I has just served
+    fill(buf<I>(), qb + 3 * (kU / kQ));
   }
 };
 
+// the serial stages' loop over blocks of kU steps: f(qb, buffer index)
+template <typename F>
+__device__ __forceinline__ void for_blocks(int64_t q_first, int64_t q_last, F f) {
+  int64_t qb = q_first;
+  while (true) {
+    if (qb > q_last) break;
+    f(qb, std::integral_constant<int, 0>{});
+    qb += kU / kQ;
+    if (qb > q_last) break;
+    f(qb, std::integral_constant<int, 1>{});
+    qb += kU / kQ;
+    if (qb > q_last) break;
+    f(qb, std::integral_constant<int, 2>{});
+    qb += kU / kQ;
+  }
+}
 
-// A block of kU steps of a serial stage that keeps per-control-block bookkeeping: the steps run in unrolled, unguarded
-// form unless a control block (or the window) ends inside the kU steps; `block_end` exists once, outside the unrolled code.
-template <typename Step, typename BlockEnd>
-__device__ __forceinline__ void run_steps(int64_t t, int64_t n, int cb, int &in_block, Step step, BlockEnd block_end) {
-  const int avail = (n - t) < kU ? (int)(n - t) : kU;
-  int u0 = 0;
-  while (u0 < avail) {
-    int seg = avail - u0;
-    if (cb - in_block < seg) seg = cb - in_block;
+// One block of kU slots of a serial stage.  The slots that belong to the window, [lo, hi), run as whole-block unrolled code
+// with vector stores when all kU do and no control block ends inside; otherwise slot by slot with element stores (the
+// window's first and last block, and the blocks a control block ends in).  `block_end` exists once, outside the unrolled code.
+template <bool kBlocks, typename Step, typename StoreAll, typename StoreOne, typename BlockEnd>
+__device__ __forceinline__ void run_block(int64_t qb, int64_t n0, int64_t n, int cb, int &in_block, Step step, StoreAll store_all,
+                                          StoreOne store_one, BlockEnd block_end) {
+  const int64_t base = qb * kQ;
+  const int lo = n0 > base ? (int)(n0 - base) : 0;
+  const int hi = (n0 + n - base) < kU ? (int)(n0 + n - base) : kU;
+  int u0 = lo;
+  while (u0 < hi) {
+    int seg = hi - u0;
+    if (kBlocks && cb - in_block < seg) seg = cb - in_block;
     if (seg == kU) {
 #pragma unroll
       for (int u = 0; u < kU; ++u) step(u);
+      store_all();
     } else {
 #pragma unroll
       for (int u = 0; u < kU; ++u)
-        if (u >= u0 && u < u0 + seg) step(u);
+        if (u >= u0 && u < u0 + seg) {
+          step(u);
+          store_one(u);
+        }
     }
-    in_block += seg;
     u0 += seg;
-    if (in_block == cb || t + u0 == n) {
-      block_end();
-      in_block = 0;
+    if (kBlocks) {
+      in_block += seg;
+      if (in_block == cb || base + u0 == n0 + n) {
+        block_end();
+        in_block = 0;
+      }
     }
   }
 }
 
-// ============================================================================================ stream-major -> time-major
-__global__ __launch_bounds__(256) void stage_tin_kernel(StageArgs a) {
-  __shared__ float tile[kTileRows][kLanes + 1];
-  const int g = blockIdx.y;
-  const Who w = who(a, g);
-  const int wave = threadIdx.x >> 6;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows;
-#pragma unroll 4
-  for (int r = wave * 16; r < wave * 16 + 16; ++r) {
-    const int s = g * kLanes + r;
-    const int64_t t = t0 + w.lane;
-    tile[w.lane][r] = (s < a.n_streams && t < a.n) ? a.in[(int64_t)s * a.stream_stride + t] : 0.0f;
+// an output ring of a serial stage: the block's kU results in registers, stored as four quads or slot by slot
+template <typename T>
+struct Out {
+  T v[kU];
+  T *base;
+  int rows, lane;
+  __device__ __forceinline__ void init(T *ring, int g, int lane_, int rows_) {
+    base = ring + (int64_t)g * rows_ * kLanes;
+    rows = rows_;
+    lane = lane_;
   }
-  __syncthreads();
-  float *xe = a.r.xe + (int64_t)g * a.r.rows_f32 * kLanes + w.lane;
-#pragma unroll 4
-  for (int tt = wave * 16; tt < wave * 16 + 16; ++tt)
-    if (t0 + tt < a.n) xe[rrow(a.n0 + t0 + tt, a.r.rows_f32)] = tile[tt][w.lane];
+  __device__ __forceinline__ void store_all(int64_t qb) {
+#pragma unroll
+    for (int k = 0; k < kU / kQ; ++k) store_quad(base + qoff(qb + k, rows) + lane * kQ, v, k);
+  }
+  __device__ __forceinline__ void store_one(int64_t qb, int u) { base[eoff(qb * kQ + u, lane, rows)] = v[u]; }
+};
+
+// elementwise feed-forward stages: a workgroup takes kFfQuads quad-rows of a group, a thread element i of each
+// (lane i >> 2, step i & 3): consecutive threads touch consecutive addresses
+constexpr int kFfQuads = 8;
+struct Elem {
+  int64_t idx;   // offset inside a group's ring
+  int64_t abs;   // absolute sample
+  bool in;       // inside the window
+};
+__device__ __forceinline__ Elem ff_elem(const StageArgs &a, int64_t q, int i, int rows) {
+  Elem e;
+  e.abs = q * kQ + (i & 3);
+  e.idx = qoff(q, rows) + i;
+  e.in = e.abs >= a.n0 && e.abs < a.n0 + a.n;
+  return e;
+}
+
+// ============================================================================================ block input statistics
+// input_square_sum (f64, in sample order) and input_sample_peak of every control block (block_processor.rs:111-118) from
+// the scrubbed input the EQ kernel leaves in the `xi` ring: two instructions on the recurrence, off the EQ's own loop
+__global__ __launch_bounds__(64) void stage_in_kernel(StageArgs a) {
+  const Who w = who(a, blockIdx.x);
+  const ChainParams &P = preset(a, w.g);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in;
+  in.init(a.r.xi, w.g, w.lane, a.r.rows_f32, q_first);
+  const int cb = P.control_block;
+  BlockStats *stats = a.stats;
+  double in_sq = 0.0;
+  float in_peak = 0.0f;
+  int in_block = 0;
+  int64_t b = 0;
+  auto block_end = [&]() {
+    if (w.valid && stats) {
+      stats[b * w.NS + w.s].input_square_sum = in_sq;
+      stats[b * w.NS + w.s].input_sample_peak = in_peak;
+    }
+    in_sq = 0.0;
+    in_peak = 0.0f;
+    b += 1;
+  };
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const float v = cur[u];
+      in_sq += (double)v * (double)v;
+      in_peak = fmaxf(in_peak, fabsf(v));
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [] {}, [](int) {}, block_end);
+    in.template refill<kBuf>(qb);
+  });
 }
 
 // ============================================================================================ compressor, serial part A
-// side-chain high-pass + band / rms envelopes (compressor.rs:700-733; the token-ring kernel's token A)
+// side-chain high-pass + band / rms envelopes (compressor.rs:700-733; the token-ring kernel's token A), as two stages of
+// about a dozen instructions per step each: (1) the high-pass, the low band's envelope and the presence signal, (2) the
+// voiced, presence and rms envelopes
+template <bool kSc>
 __global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) {
   const Who w = who(a, blockIdx.x);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
   Ahead<float> in;
-  in.init(a.r.xe, w.g, w.lane, a.r.rows_f32, a.n0);
-  const int R = a.r.rows_f64;
-  const int64_t gb = (int64_t)w.g * R * kLanes + w.lane;
-  double *o_d = a.r.d + gb, *o_low = a.r.low_e + gb, *o_voiced = a.r.voiced_e + gb, *o_pres = a.r.pres_e + gb, *o_rms = a.r.rms_e + gb;
-  double rms_env = a.st64[(int64_t)kCompRmsEnvSq * w.NS + w.sc];
+  in.init(a.r.xe, w.g, w.lane, a.r.rows_f32, q_first);
+  Out<double> o_d, o_low, o_pr;
+  o_d.init(a.r.d, w.g, w.lane, a.r.rows_f64);
+  if (kSc) {
+    o_low.init(a.r.low_e, w.g, w.lane, a.r.rows_f64);
+    o_pr.init(a.r.pr, w.g, w.lane, a.r.rows_f64);
+  }
   double prev_in = a.st64[(int64_t)kCompScPrevIn * w.NS + w.sc], prev_out = a.st64[(int64_t)kCompScPrevOut * w.NS + w.sc];
-  double low_env = a.st64[(int64_t)kCompLowEnv * w.NS + w.sc], voiced_env = a.st64[(int64_t)kCompVoicedEnv * w.NS + w.sc];
-  double presence_env = a.st64[(int64_t)kCompPresenceEnv * w.NS + w.sc];
+  double low_env = a.st64[(int64_t)kCompLowEnv * w.NS + w.sc];
   // every parameter the loop reads is copied out first: read through the parameter pointer it would be re-loaded from
   // memory at every step (the loop's stores could alias it), each time behind a wait for ALL outstanding memory traffic
-  const bool sc_on = cp.sidechain_highpass_enabled != 0;
-  const double kk = cp.band_env_coeff, sc_coeff = cp.sidechain_highpass_coeff, rms_coeff = cp.rms_coeff;
-  const int64_t n = a.n, n0 = a.n0;
-  auto step = [&](int64_t t, float x) {
-    const int64_t row = rrow(n0 + t, R);
-    const double xin = (double)x;
-    if (sc_on) {
-      const double dd = sc_coeff * (prev_out + xin - prev_in);
-      prev_in = xin;
-      prev_out = dd;
-      const double low = xin - dd;
-      const double presence = 0.65 * dd + 0.35 * (dd - low);
-      low_env = kk * low_env + (1.0 - kk) * low * low;
-      voiced_env = kk * voiced_env + (1.0 - kk) * dd * dd;
-      presence_env = kk * presence_env + (1.0 - kk) * presence * presence;
-      rms_env = rms_coeff * rms_env + (1.0 - rms_coeff) * (dd * dd);
-      o_d[row] = dd;
-      o_low[row] = low_env;
-      o_voiced[row] = voiced_env;
-      o_pres[row] = presence_env;
-      o_rms[row] = rms_env;
-    } else {
-      const double dd = xin;
-      rms_env = rms_coeff * rms_env + (1.0 - rms_coeff) * (dd * dd);
-      o_d[row] = dd;
-      o_rms[row] = rms_env;
-    }
-  };
-  for (int64_t t = 0; t < n; t += kU) {
-    if (t + kU <= n) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) step(t + u, in.cur[u]);
-    } else {
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (t + u < n) step(t + u, in.cur[u]);
-    }
-    in.advance(t);
+  const double kk = cp.band_env_coeff, sc_coeff = cp.sidechain_highpass_coeff;
+  const double one_m_kk = 1.0 - kk;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const double xin = (double)cur[u];
+      if (kSc) {
+        const double dd = sc_coeff * (prev_out + xin - prev_in);
+        prev_in = xin;
+        prev_out = dd;
+        const double low = xin - dd;
+        const double presence = 0.65 * dd + 0.35 * (dd - low);
+        low_env = kk * low_env + one_m_kk * low * low;
+        o_d.v[u] = dd;
+        o_pr.v[u] = presence;
+        o_low.v[u] = low_env;
+      } else {
+        o_d.v[u] = xin;
+      }
+    };
+    auto store_all = [&]() {
+      o_d.store_all(qb);
+      if (kSc) {
+        o_low.store_all(qb);
+        o_pr.store_all(qb);
+      }
+    };
+    auto store_one = [&](int u) {
+      o_d.store_one(qb, u);
+      if (kSc) {
+        o_low.store_one(qb, u);
+        o_pr.store_one(qb, u);
+      }
+    };
+    run_block<false>(qb, n0, n, 0, dummy, step, store_all, store_one, [] {});
+    in.template refill<kBuf>(qb);
+  });
+  if (w.valid && kSc) {
+    a.st64[(int64_t)kCompScPrevIn * w.NS + w.s] = prev_in;
+    a.st64[(int64_t)kCompScPrevOut * w.NS + w.s] = prev_out;
+    a.st64[(int64_t)kCompLowEnv * w.NS + w.s] = low_env;
   }
+}
+
+template <bool kSc>
+__global__ __launch_bounds__(64) void stage_comp_a2_kernel(StageArgs a) {
+  const Who w = who(a, blockIdx.x);
+  const ChainParams &P = preset(a, w.g);
+  const CompressorParams &cp = P.comp;
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<double> in_d, in_pr;
+  in_d.init(a.r.d, w.g, w.lane, a.r.rows_f64, q_first);
+  if (kSc) in_pr.init(a.r.pr, w.g, w.lane, a.r.rows_f64, q_first);
+  Out<double> o_voiced, o_pres, o_rms;
+  o_rms.init(a.r.rms_e, w.g, w.lane, a.r.rows_f64);
+  if (kSc) {
+    o_voiced.init(a.r.voiced_e, w.g, w.lane, a.r.rows_f64);
+    o_pres.init(a.r.pres_e, w.g, w.lane, a.r.rows_f64);
+  }
+  double rms_env = a.st64[(int64_t)kCompRmsEnvSq * w.NS + w.sc];
+  double voiced_env = a.st64[(int64_t)kCompVoicedEnv * w.NS + w.sc], presence_env = a.st64[(int64_t)kCompPresenceEnv * w.NS + w.sc];
+  const double kk = cp.band_env_coeff, rms_coeff = cp.rms_coeff;
+  const double one_m_kk = 1.0 - kk, one_m_rms = 1.0 - rms_coeff;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur_d)[kU] = in_d.template buf<kBuf>();
+    const double(&cur_pr)[kU] = in_pr.template buf<kBuf>();
+    auto step = [&](int u) {
+      const double dd = cur_d[u];
+      if (kSc) {
+        const double presence = cur_pr[u];
+        voiced_env = kk * voiced_env + one_m_kk * dd * dd;
+        presence_env = kk * presence_env + one_m_kk * presence * presence;
+        o_voiced.v[u] = voiced_env;
+        o_pres.v[u] = presence_env;
+      }
+      rms_env = rms_coeff * rms_env + one_m_rms * (dd * dd);
+      o_rms.v[u] = rms_env;
+    };
+    auto store_all = [&]() {
+      o_rms.store_all(qb);
+      if (kSc) {
+        o_voiced.store_all(qb);
+        o_pres.store_all(qb);
+      }
+    };
+    auto store_one = [&](int u) {
+      o_rms.store_one(qb, u);
+      if (kSc) {
+        o_voiced.store_one(qb, u);
+        o_pres.store_one(qb, u);
+      }
+    };
+    run_block<false>(qb, n0, n, 0, dummy, step, store_all, store_one, [] {});
+    in_d.template refill<kBuf>(qb);
+    if (kSc) in_pr.template refill<kBuf>(qb);
+  });
   if (w.valid) {
     a.st64[(int64_t)kCompRmsEnvSq * w.NS + w.s] = rms_env;
-    if (sc_on) {
-      a.st64[(int64_t)kCompScPrevIn * w.NS + w.s] = prev_in;
-      a.st64[(int64_t)kCompScPrevOut * w.NS + w.s] = prev_out;
-      a.st64[(int64_t)kCompLowEnv * w.NS + w.s] = low_env;
+    if (kSc) {
       a.st64[(int64_t)kCompVoicedEnv * w.NS + w.s] = voiced_env;
       a.st64[(int64_t)kCompPresenceEnv * w.NS + w.s] = presence_env;
     }
@@ -199,18 +384,18 @@ __global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) {
 // detector weight, instantaneous peak and RMS levels in dB (update_sidechain_band_metrics, compressor.rs:438-449)
 __global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) {
   const int g = blockIdx.y;
-  const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
   const CompressorParams cp = P.comp;  // by value: fields read through the pointer would be re-loaded after every store
-  const int wave = threadIdx.x >> 6;
   const int R = a.r.rows_f64;
-  const int64_t gb = (int64_t)g * R * kLanes + w.lane;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows + wave * 16;
-  const int64_t n = a.n;
-  for (int k = 0; k < 16; ++k) {
-    const int64_t t = t0 + k;
-    if (t >= n) break;
-    const int64_t row = gb + rrow(a.n0 + t, R);
+  const int64_t gb = (int64_t)g * R * kLanes;
+  const int i = threadIdx.x, lane = i >> 2;
+  const int s = g * kLanes + lane;
+  const int64_t NS = a.n_streams;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const int64_t row = gb + e.idx;
     double weight_db = 0.0, plosive_last = 0.0;
     if (cp.sidechain_highpass_enabled) {
       const double low_rms = sqrt(a.r.low_e[row]);
@@ -227,7 +412,7 @@ __global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) {
     a.r.w_db[row] = weight_db;
     a.r.ipk_db[row] = lin2db(fabs(a.r.d[row]), 1e-10);
     a.r.rms_db[row] = lin2db(sqrt(a.r.rms_e[row]), 1e-10);
-    if (t == n - 1 && w.valid) a.st64[(int64_t)kCompPlosive * w.NS + w.s] = plosive_last;  // diagnostic state only
+    if (e.abs == a.n0 + a.n - 1 && s < a.n_streams) a.st64[(int64_t)kCompPlosive * NS + s] = plosive_last;  // diagnostic state only
   }
 }
 
@@ -238,29 +423,32 @@ __global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) {
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
   Ahead<double> in;
-  in.init(a.r.ipk_db, w.g, w.lane, a.r.rows_f64, a.n0);
-  const int R = a.r.rows_f64;
-  double *o = a.r.peak_db + (int64_t)w.g * R * kLanes + w.lane;
+  in.init(a.r.ipk_db, w.g, w.lane, a.r.rows_f64, q_first);
+  Out<double> o;
+  o.init(a.r.peak_db, w.g, w.lane, a.r.rows_f64);
   double pe = a.st64[(int64_t)kCompPeakEnvDb * w.NS + w.sc];
   const double attack_coeff = cp.attack_coeff, detector_release_coeff = cp.detector_release_coeff;
-  const int64_t n = a.n, n0 = a.n0;
-  auto step = [&](int64_t t, double v) {
-    const double pk = v > pe ? attack_coeff : detector_release_coeff;
-    pe = pk * pe + (1.0 - pk) * v;
-    o[rrow(n0 + t, R)] = pe;
-  };
-  for (int64_t t = 0; t < n; t += kU) {
-    if (t + kU <= n) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) step(t + u, in.cur[u]);
-    } else {
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (t + u < n) step(t + u, in.cur[u]);
-    }
-    in.advance(t);
-  }
+  // both candidates of the one-pole step are formed before the comparison picks one: the same operations on the same
+  // values as `pk = v > pe ? attack : release; pe = pk * pe + (1 - pk) * v`, but only mul -> add -> select sits on the
+  // recurrence's critical path (the products with v do not depend on pe)
+  const double one_m_attack = 1.0 - attack_coeff, one_m_release = 1.0 - detector_release_coeff;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const double v = cur[u];
+      const double rising = attack_coeff * pe + one_m_attack * v;
+      const double falling = detector_release_coeff * pe + one_m_release * v;
+      pe = v > pe ? rising : falling;
+      o.v[u] = pe;
+    };
+    run_block<false>(qb, n0, n, 0, dummy, step, [&] { o.store_all(qb); }, [&](int u) { o.store_one(qb, u); }, [] {});
+    in.template refill<kBuf>(qb);
+  });
   if (w.valid) a.st64[(int64_t)kCompPeakEnvDb * w.NS + w.s] = pe;
 }
 
@@ -268,18 +456,16 @@ __global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) {
 // blended detector level -> static gain-reduction target (compressor.rs:744-750,657-678)
 __global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) {
   const int g = blockIdx.y;
-  const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
-  const CompressorParams cp = P.comp;  // by value: fields read through the pointer would be re-loaded after every store
-  const int wave = threadIdx.x >> 6;
+  const CompressorParams cp = P.comp;
   const int R = a.r.rows_f64;
-  const int64_t gb = (int64_t)g * R * kLanes + w.lane;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows + wave * 16;
-  const int64_t n = a.n;
-  for (int k = 0; k < 16; ++k) {
-    const int64_t t = t0 + k;
-    if (t >= n) break;
-    const int64_t row = gb + rrow(a.n0 + t, R);
+  const int64_t gb = (int64_t)g * R * kLanes;
+  const int i = threadIdx.x;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const int64_t row = gb + e.idx;
     const double blended = 0.6 * db2lin(a.r.peak_db[row]) + 0.4 * db2lin(a.r.rms_db[row]);
     a.r.target[row] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + a.r.w_db[row]);
   }
@@ -287,15 +473,18 @@ __global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) {
 
 // ============================================================================================ compressor, serial part E
 // release-time meter + gain-reduction smoothing, makeup gain per control block (compressor.rs:452-505,604-617,752-764)
+template <bool kAdaptive>
 __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
   const Who w = who(a, blockIdx.x);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
   Ahead<double> in;
-  in.init(a.r.target, w.g, w.lane, a.r.rows_f64, a.n0);
-  const int R = a.r.rows_f64;
-  double *o = a.r.gr + (int64_t)w.g * R * kLanes + w.lane;
+  in.init(a.r.target, w.g, w.lane, a.r.rows_f64, q_first);
+  Out<double> o;
+  o.init(a.r.gr, w.g, w.lane, a.r.rows_f64);
   double gr = a.st64[(int64_t)kCompGr * w.NS + w.sc], fast = a.st64[(int64_t)kCompFastEnv * w.NS + w.sc];
   double slow = a.st64[(int64_t)kCompSlowEnv * w.NS + w.sc];
   double cur_ms = a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.sc], tgt_ms = a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.sc];
@@ -303,51 +492,15 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
   double sm = a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.sc];
   double makeup_lin = db2lin(sm);
   const int cb = P.control_block;
-  const bool adaptive = cp.adaptive_release != 0;
   const double base_release_ms = cp.base_release_ms, release_smoothing_coeff = cp.release_smoothing_coeff;
   const double attack_coeff = cp.attack_coeff, fast_release_coeff = cp.fast_release_coeff, slow_charge_coeff = cp.slow_charge_coeff;
   const double slow_release_coeff = cp.slow_release_coeff, makeup_smoothing_coeff = cp.makeup_smoothing_coeff, makeup_gain_db = cp.makeup_gain_db;
   const double sample_rate = cp.sample_rate;
-  const int64_t n = a.n, n0 = a.n0;
   double *mk = a.mk;
   BlockStats *stats = a.stats;
   int in_block = 0;
   int64_t b = 0;
   if (w.valid) mk[w.s] = makeup_lin;  // the gain in force during the window's first block
-  auto step = [&](int64_t t, double tg) {
-    if (adaptive) {
-      const double sustained = dclamp(div_known(slow, 6.0, 1.0 / 6.0), 0.0, 1.0);
-      const double transient_bias = dclamp(div_known(fast - slow, 7.0, 1.0 / 7.0), 0.0, 1.0);
-      const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
-      tgt_ms = 50.0 + syllabic * (400.0 - 50.0);
-    } else {
-      tgt_ms = base_release_ms;
-    }
-    if (fabs(tgt_ms - cur_ms) > 1.0) {
-      cur_ms = release_smoothing_coeff * cur_ms + (1.0 - release_smoothing_coeff) * tgt_ms;
-    } else {
-      cur_ms = tgt_ms;
-    }
-    if (!adaptive) {
-      const double kk = tg > gr ? attack_coeff : rel_coeff;
-      gr = kk * gr + (1.0 - kk) * tg;
-      fast = gr;
-      slow = 0.0;
-    } else {
-      if (tg > gr) {
-        fast = attack_coeff * gr + (1.0 - attack_coeff) * tg;
-      } else {
-        fast = fast_release_coeff * fast + (1.0 - fast_release_coeff) * tg;
-      }
-      if (tg > 3.0) {
-        slow = slow_charge_coeff * slow + (1.0 - slow_charge_coeff) * tg;
-      } else {
-        slow *= slow_release_coeff;
-      }
-      gr = fmax(fast, slow);
-    }
-    o[rrow(n0 + t, R)] = gr;
-  };
   auto block_end = [&]() {  // wave-uniform: a control block (or the window) ends after the step just made
     const int blk_len = in_block;
     if (w.valid && stats) stats[b * w.NS + w.s].compressor_gr_db = (float)gr;
@@ -364,10 +517,46 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
     b += 1;
     if (w.valid) mk[b * w.NS + w.s] = makeup_lin;  // ... and during the next one
   };
-  for (int64_t t = 0; t < n; t += kU) {
-    run_steps(t, n, cb, in_block, [&](int u) { step(t + u, in.cur[u]); }, block_end);
-    in.advance(t);
-  }
+  const double one_m_attack = 1.0 - attack_coeff, one_m_rel = 1.0 - rel_coeff, one_m_fast = 1.0 - fast_release_coeff;
+  const double one_m_charge = 1.0 - slow_charge_coeff, one_m_smooth = 1.0 - release_smoothing_coeff;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const double tg = cur[u];
+      if (kAdaptive) {
+        const double sustained = dclamp(div_known(slow, 6.0, 1.0 / 6.0), 0.0, 1.0);
+        const double transient_bias = dclamp(div_known(fast - slow, 7.0, 1.0 / 7.0), 0.0, 1.0);
+        const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
+        tgt_ms = 50.0 + syllabic * (400.0 - 50.0);
+      } else {
+        tgt_ms = base_release_ms;
+      }
+      {
+        const double smoothed = release_smoothing_coeff * cur_ms + one_m_smooth * tgt_ms;
+        cur_ms = fabs(tgt_ms - cur_ms) > 1.0 ? smoothed : tgt_ms;
+      }
+      // (both candidates of every one-pole step are formed before the comparison picks one: same operations, same values)
+      if (!kAdaptive) {
+        const double rising = attack_coeff * gr + one_m_attack * tg;
+        const double falling = rel_coeff * gr + one_m_rel * tg;
+        gr = tg > gr ? rising : falling;
+        fast = gr;
+        slow = 0.0;
+      } else {
+        const double rising = attack_coeff * gr + one_m_attack * tg;
+        const double falling = fast_release_coeff * fast + one_m_fast * tg;
+        fast = tg > gr ? rising : falling;
+        const double charged = slow_charge_coeff * slow + one_m_charge * tg;
+        const double released = slow * slow_release_coeff;
+        slow = tg > 3.0 ? charged : released;
+        gr = fmax(fast, slow);
+      }
+      o.v[u] = gr;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o.store_all(qb); }, [&](int u) { o.store_one(qb, u); }, block_end);
+    in.template refill<kBuf>(qb);
+  });
   if (w.valid) {
     a.st64[(int64_t)kCompGr * w.NS + w.s] = gr;
     a.st64[(int64_t)kCompFastEnv * w.NS + w.s] = fast;
@@ -375,7 +564,7 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
     a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.s] = cur_ms;
     a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.s] = tgt_ms;
     a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
-    if (adaptive) {
+    if (kAdaptive) {
       const double tau = fmax(cur_ms, 0.001) / 1000.0;  // compressor.rs:760-761
       a.st64[(int64_t)kCompReleaseCoeff * w.NS + w.s] = exp(-1.0 / (tau * sample_rate));
     }
@@ -386,19 +575,21 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
 // apply gain (compressor.rs:771-773)
 __global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) {
   const int g = blockIdx.y;
-  const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
-  const int wave = threadIdx.x >> 6;
   const int R = a.r.rows_f64, R32 = a.r.rows_f32;
-  const int64_t gb = (int64_t)g * R * kLanes + w.lane, gb32 = (int64_t)g * R32 * kLanes + w.lane;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows + wave * 16;
+  const int64_t gb = (int64_t)g * R * kLanes, gb32 = (int64_t)g * R32 * kLanes;
+  const int i = threadIdx.x, lane = i >> 2;
+  const int s = g * kLanes + lane;
+  const int sc = s < a.n_streams ? s : a.n_streams - 1;
+  const int64_t NS = a.n_streams;
   const int cb = P.control_block;
-  for (int k = 0; k < 16; ++k) {
-    const int64_t t = t0 + k;
-    if (t >= a.n) break;
-    const double makeup_lin = a.mk[(t / cb) * w.NS + w.sc];
-    const double gr = a.r.gr[gb + rrow(a.n0 + t, R)];
-    const int64_t row = gb32 + rrow(a.n0 + t, R32);
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const double makeup_lin = a.mk[((e.abs - a.n0) / cb) * NS + sc];
+    const double gr = a.r.gr[gb + e.idx];
+    const int64_t row = gb32 + qoff(q0 + k, R32) + i;
     a.r.xc[row] = (float)((double)a.r.xe[row] * (db2lin(-gr) * makeup_lin));
   }
 }
@@ -414,14 +605,15 @@ __global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *
   const int W = P.lim.lookahead_samples + 1;
   const double ceil_lin = P.lim.ceiling_linear;
   const int R32 = a.r.rows_f32, R = a.r.rows_f64;
-  const float *x = xin_ring + (int64_t)g * R32 * kLanes + w.lane;
-  float *sfx = a.r.sfx + (int64_t)g * R32 * kLanes + w.lane;
-  double *tg = a.r.tg + (int64_t)g * R * kLanes + w.lane;
+  const float *x = xin_ring + (int64_t)g * R32 * kLanes;
+  float *sfx = a.r.sfx + (int64_t)g * R32 * kLanes;
+  double *tg = a.r.tg + (int64_t)g * R * kLanes;
+  const int lane = w.lane;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
   // blocks are aligned to absolute multiples of W
-  const int64_t first = a.n0 / W;
-  const int64_t B = first + blockIdx.x;
+  const int64_t B = n0 / W + blockIdx.x;
   const int64_t b0 = B * W;
-  if (b0 >= a.n0 + a.n) return;
+  if (b0 >= n_end) return;
   // suffix maxima of block B - 1, eight loads at a time
   {
     float m = 0.0f;
@@ -429,47 +621,47 @@ __global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *
     for (; j >= 7; j -= 8) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = fabsf(x[rrow(b0 - W + j - u, R32)]);
+      for (int u = 0; u < 8; ++u) v[u] = fabsf(x[eoff(b0 - W + j - u, lane, R32)]);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         m = fmaxf(m, v[u]);
-        sfx[rrow(b0 - W + j - u, R32)] = m;
+        sfx[eoff(b0 - W + j - u, lane, R32)] = m;
       }
     }
     for (; j >= 0; --j) {
-      m = fmaxf(m, fabsf(x[rrow(b0 - W + j, R32)]));
-      sfx[rrow(b0 - W + j, R32)] = m;
+      m = fmaxf(m, fabsf(x[eoff(b0 - W + j, lane, R32)]));
+      sfx[eoff(b0 - W + j, lane, R32)] = m;
     }
   }
-  // forward over block B: running prefix maximum, output for the rows that belong to this window
+  // forward over block B: running prefix maximum, output for the samples that belong to this window
   float prefix = 0.0f;
-  const int64_t end = (b0 + W < a.n0 + a.n) ? b0 + W : a.n0 + a.n;
+  const int64_t end = (b0 + W < n_end) ? b0 + W : n_end;
   int64_t n = b0;
   for (; n + 8 <= end; n += 8) {
     float v[8], sf[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      v[u] = fabsf(x[rrow(n + u, R32)]);
+      v[u] = fabsf(x[eoff(n + u, lane, R32)]);
       const int64_t j = n + u - b0;
-      sf[u] = (j + 1 < W) ? sfx[rrow(b0 - W + j + 1, R32)] : 0.0f;
+      sf[u] = (j + 1 < W) ? sfx[eoff(b0 - W + j + 1, lane, R32)] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       prefix = (n + u == b0) ? v[u] : fmaxf(prefix, v[u]);
-      if (n + u >= a.n0) {
+      if (n + u >= n0) {
         const double peak = (double)fmaxf(sf[u], prefix);
-        tg[rrow(n + u, R)] = peak > ceil_lin ? ceil_lin / peak : 1.0;
+        tg[eoff(n + u, lane, R)] = peak > ceil_lin ? ceil_lin / peak : 1.0;
       }
     }
   }
   for (; n < end; ++n) {
-    const float ax = fabsf(x[rrow(n, R32)]);
+    const float ax = fabsf(x[eoff(n, lane, R32)]);
     const int64_t j = n - b0;
-    const float sf = (j + 1 < W) ? sfx[rrow(b0 - W + j + 1, R32)] : 0.0f;
+    const float sf = (j + 1 < W) ? sfx[eoff(b0 - W + j + 1, lane, R32)] : 0.0f;
     prefix = (n == b0) ? ax : fmaxf(prefix, ax);
-    if (n >= a.n0) {
+    if (n >= n0) {
       const double peak = (double)fmaxf(sf, prefix);
-      tg[rrow(n, R)] = peak > ceil_lin ? ceil_lin / peak : 1.0;
+      tg[eoff(n, lane, R)] = peak > ceil_lin ? ceil_lin / peak : 1.0;
     }
   }
 }
@@ -480,180 +672,236 @@ __global__ __launch_bounds__(64) void stage_lim_kernel(StageArgs a) {
   const Who w = who(a, blockIdx.x);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
   Ahead<double> in;
-  in.init(a.r.tg, w.g, w.lane, a.r.rows_f64, a.n0);
-  const int R = a.r.rows_f64;
-  double *o = a.r.g + (int64_t)w.g * R * kLanes + w.lane;
+  in.init(a.r.tg, w.g, w.lane, a.r.rows_f64, q_first);
+  Out<double> o;
+  o.init(a.r.g, w.g, w.lane, a.r.rows_f64);
   const double rc = P.lim.release_coeff;
   double g = a.st64[(int64_t)kLimGain * w.NS + w.sc];
   double gmin = 1.0;
   const int cb = P.control_block;
-  const int64_t n = a.n, n0 = a.n0;
   BlockStats *stats = a.stats;
   int in_block = 0;
   int64_t b = 0;
-  auto step = [&](int64_t t, double tg) {
-    if (tg < g) {
-      g = tg;
-    } else {
-      g = rc * g + (1.0 - rc) * tg;
-    }
-    gmin = fmin(gmin, g);
-    o[rrow(n0 + t, R)] = g;
-  };
   auto block_end = [&]() {
     if (w.valid && stats) stats[b * w.NS + w.s].limiter_peak_gr_db = gmin < 1.0 ? (float)(-lin2db(gmin, 1e-10)) : 0.0f;
     gmin = 1.0;
     b += 1;
   };
-  for (int64_t t = 0; t < n; t += kU) {
-    run_steps(t, n, cb, in_block, [&](int u) { step(t + u, in.cur[u]); }, block_end);
-    in.advance(t);
-  }
+  const double one_m_rc = 1.0 - rc;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const double tg = cur[u];
+      const double released = rc * g + one_m_rc * tg;
+      g = tg < g ? tg : released;
+      gmin = fmin(gmin, g);
+      o.v[u] = g;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o.store_all(qb); }, [&](int u) { o.store_one(qb, u); }, block_end);
+    in.template refill<kBuf>(qb);
+  });
   if (w.valid) a.st64[(int64_t)kLimGain * w.NS + w.s] = g;
 }
 
 // ============================================================================================ feed-forward 5
 // limiter output (limiter.rs:278-284), input-side 4x true peak (true_peak.rs:173-186,341-352) and the gain it asks for.
-// A workgroup owns 64 rows of a group; the limiter output of those rows and of the 31 before them goes through LDS.
-__device__ __forceinline__ float tp_observe_regs(const float (&h)[kTpTaps + 15], int i) {
-  // the window of row i: h[i + 31 - k] is the sample k steps back
-  float peak = fabsf(h[i + kTpTaps - 1]);
+// A workgroup owns 64 steps of a group (aligned to absolute multiples of 64); the limiter output of those steps and of the
+// 32 before them goes through LDS.
+template <int kN>
+__device__ __forceinline__ float tp_observe_regs(const float (&h)[kN], int i) {
+  // the window of the sample in h[i]: h[i - k] is the sample k steps back
+  float peak = fabsf(h[i]);
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     float acc = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kTpTaps; ++k) acc = __builtin_fmaf(AF_TP_FIR[p][k], h[i + kTpTaps - 1 - k], acc);
+    for (int k = 0; k < kTpTaps; ++k) acc = __builtin_fmaf(AF_TP_FIR[p][k], h[i - k], acc);
     peak = fmaxf(peak, fabsf(acc));
   }
   return peak;
 }
 
 __global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float *xin_ring) {
-  __shared__ float xl_t[kTileRows + kTpTaps - 1][kLanes];
+  __shared__ float xl_t[kTileRows + kTpTaps][kLanes];
   const int g = blockIdx.y;
   const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
   const int wave = threadIdx.x >> 6;
   const int R32 = a.r.rows_f32, R = a.r.rows_f64;
-  const int64_t gb32 = (int64_t)g * R32 * kLanes + w.lane, gb = (int64_t)g * R * kLanes + w.lane;
+  const int64_t gb32 = (int64_t)g * R32 * kLanes, gb = (int64_t)g * R * kLanes;
   const int la = P.lim.lookahead_samples;
   const double ceil_lin = P.lim.ceiling_linear;
   const float tp_ceiling = P.tp.ceiling_linear;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows;  // window-relative first row of the tile
-  // rows t0 - 31 .. t0 + 63 of the limiter output (rows before the stream's first sample: the rings hold zeros)
-  for (int i = wave; i < kTileRows + kTpTaps - 1; i += 4) {
-    const int64_t n = a.n0 + t0 - (kTpTaps - 1) + i;
-    const float delayed = xin_ring[gb32 + rrow(n - la, R32)];
-    const double gain = a.r.g[gb + rrow(n, R)];
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t abs0 = ((n0 >> 6) + blockIdx.x) * kTileRows;  // first sample of the tile
+  // samples abs0 - 32 .. abs0 + 63 of the limiter output (before the stream's first sample the rings hold zeros)
+  for (int i = wave; i < kTileRows + kTpTaps; i += 4) {
+    const int64_t n = abs0 - kTpTaps + i;
+    const float delayed = xin_ring[gb32 + eoff(n - la, w.lane, R32)];
+    const double gain = a.r.g[gb + eoff(n, w.lane, R)];
     const float o = (float)dclamp((double)delayed * gain, -ceil_lin, ceil_lin);
     const float v = finite_f32(o) ? o : 0.0f;  // TruePeakLimiter input scrub, true_peak.rs:342
     xl_t[i][w.lane] = v;
-    if (i >= kTpTaps - 1 && t0 + i - (kTpTaps - 1) < a.n) a.r.xl[gb32 + rrow(n, R32)] = v;
+    if (n >= n0 && n < n_end && i >= kTpTaps) a.r.xl[gb32 + eoff(n, w.lane, R32)] = v;
   }
   __syncthreads();
-  float h[kTpTaps + 15];
+  float h[kTpTaps + 16];  // h[i]: sample abs0 + 16 * wave - 32 + i
 #pragma unroll
-  for (int i = 0; i < kTpTaps + 15; ++i) h[i] = xl_t[wave * 16 + i][w.lane];
+  for (int i = 0; i < kTpTaps + 16; ++i) h[i] = xl_t[wave * 16 + i][w.lane];
+  float itp_v[16], tgt_v[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int64_t t = t0 + wave * 16 + k;
-    if (t < a.n) {
-      const float itp = tp_observe_regs(h, k);
-      float tg = 1.0f;
-      if (itp > tp_ceiling) tg = fclamp((tp_ceiling * 0.999f) / itp, 0.0f, 1.0f);
-      a.r.itp[gb32 + rrow(a.n0 + t, R32)] = itp;
-      a.r.tgt[gb32 + rrow(a.n0 + t, R32)] = tg;
+    const float itp = tp_observe_regs(h, kTpTaps + k);
+    float tg = 1.0f;
+    if (itp > tp_ceiling) tg = fclamp((tp_ceiling * 0.999f) / itp, 0.0f, 1.0f);
+    itp_v[k] = itp;
+    tgt_v[k] = tg;
+  }
+  const int64_t first = abs0 + wave * 16;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t qa = first + 4 * k;
+    float *pi = a.r.itp + gb32 + qoff(qa >> 2, R32) + w.lane * kQ, *pt = a.r.tgt + gb32 + qoff(qa >> 2, R32) + w.lane * kQ;
+    if (qa >= n0 && qa + 3 < n_end) {
+      *reinterpret_cast<float4 *>(pi) = make_float4(itp_v[4 * k], itp_v[4 * k + 1], itp_v[4 * k + 2], itp_v[4 * k + 3]);
+      *reinterpret_cast<float4 *>(pt) = make_float4(tgt_v[4 * k], tgt_v[4 * k + 1], tgt_v[4 * k + 2], tgt_v[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (qa + j >= n0 && qa + j < n_end) {
+          pi[j] = itp_v[4 * k + j];
+          pt[j] = tgt_v[4 * k + j];
+        }
     }
   }
 }
 
-// ============================================================================================ true-peak limiter, serial part
-// gain (true_peak.rs:353-374), chain output, block output statistics (block_processor.rs:150-170)
-template <bool kLim>
-__global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a, const float *xin_ring) {
+// ============================================================================================ true-peak limiter, serial parts
+// (1) the gain (true_peak.rs:353-374) and the limiter's own block figures; (2) the chain output and the block output
+// statistics (block_processor.rs:150-170), whose square sum is a recurrence of its own
+__global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a) {
   const Who w = who(a, blockIdx.x);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
   const int R32 = a.r.rows_f32;
-  Ahead<float> in_x, in_itp, in_tgt;
-  if (kLim) {
-    in_x.init(a.r.xl, w.g, w.lane, R32, a.n0, -kTpDelay);
-    in_itp.init(a.r.itp, w.g, w.lane, R32, a.n0);
-    in_tgt.init(a.r.tgt, w.g, w.lane, R32, a.n0);
-  } else {
-    in_x.init(xin_ring, w.g, w.lane, R32, a.n0);
-  }
-  float *o_ring = a.r.od + (int64_t)w.g * R32 * kLanes + w.lane;
-  const float tp_ceiling = P.tp.ceiling_linear;
-  const float rel = P.tp.release_coeff;
-  const bool comp_on = (P.flags & kFlagCompressor) != 0;
-  float g = kLim ? a.st32[(int64_t)kTpGain * w.NS + w.sc] : 1.0f;
-  double out_sq = 0.0;
-  float out_peak = 0.0f, nonfinite = 0.0f, tp_in_peak = 0.0f, tp_gmin = 1.0f, tp_limited = 0.0f;
-  const int cb = P.control_block;
   const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in_itp, in_tgt;
+  in_itp.init(a.r.itp, w.g, w.lane, R32, q_first);
+  in_tgt.init(a.r.tgt, w.g, w.lane, R32, q_first);
+  Out<float> o_g;
+  o_g.init(a.r.gt, w.g, w.lane, R32);
+  const float rel = P.tp.release_coeff;
+  const float one_m_rel = 1.0f - rel;
+  float g = a.st32[(int64_t)kTpGain * w.NS + w.sc];
+  float tp_in_peak = 0.0f, tp_gmin = 1.0f, tp_limited = 0.0f;
+  const int cb = P.control_block;
   BlockStats *stats = a.stats;
   int in_block = 0;
   int64_t b = 0;
-  auto step = [&](int64_t t, float delayed, float itp, float tg) {
-    float o = delayed;
-    if (kLim) {
-      tp_in_peak = fmaxf(tp_in_peak, itp);
-      if (tg < g) {
-        g = tg;
-        tp_limited = 1.0f;
-      } else {
-        g = rel * g + (1.0f - rel) * tg;
-      }
-      tp_gmin = fminf(tp_gmin, g);
-      o = fclamp(delayed * g, -tp_ceiling, tp_ceiling);
-      if (!finite_f32(o)) o = 0.0f;
+  auto block_end = [&]() {
+    if (w.valid && stats) {
+      BlockStats &row = stats[b * w.NS + w.s];
+      row.tp_limiter_input_peak = tp_in_peak;
+      row.tp_limiter_gr_db = tp_gmin < 1.0f ? -20.0f * log10f(fmaxf(tp_gmin, 1e-10f)) : 0.0f;
+      row.tp_limited_events = tp_limited != 0.0f ? 1u : 0u;
     }
-    if (finite_f32(o)) {
-      out_sq += (double)o * (double)o;
-    } else {
-      nonfinite = 1.0f;
-    }
-    out_peak = fmaxf(out_peak, fabsf(o));
-    o_ring[rrow(n0 + t, R32)] = o;
+    tp_in_peak = 0.0f;
+    tp_gmin = 1.0f;
+    tp_limited = 0.0f;
+    b += 1;
   };
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur_itp)[kU] = in_itp.template buf<kBuf>();
+    const float(&cur_tgt)[kU] = in_tgt.template buf<kBuf>();
+    auto step = [&](int u) {
+      const float itp = cur_itp[u], tg = cur_tgt[u];
+      tp_in_peak = fmaxf(tp_in_peak, itp);
+      const float released = rel * g + one_m_rel * tg;  // (formed before the comparison picks: same operations, same values)
+      const bool limiting = tg < g;
+      tp_limited = limiting ? 1.0f : tp_limited;
+      g = limiting ? tg : released;
+      tp_gmin = fminf(tp_gmin, g);
+      o_g.v[u] = g;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o_g.store_all(qb); }, [&](int u) { o_g.store_one(qb, u); }, block_end);
+    in_itp.template refill<kBuf>(qb);
+    in_tgt.template refill<kBuf>(qb);
+  });
+  if (w.valid) a.st32[(int64_t)kTpGain * w.NS + w.s] = g;
+}
+
+template <bool kLim>
+__global__ __launch_bounds__(64) void stage_out_kernel(StageArgs a, const float *xin_ring) {
+  const Who w = who(a, blockIdx.x);
+  const ChainParams &P = preset(a, w.g);
+  __builtin_amdgcn_s_setprio(3);
+  const int R32 = a.r.rows_f32;
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in_x, in_g;
+  if (kLim) {
+    static_assert(kTpDelay % kQ == 0, "the true-peak delay must be a whole number of quads");
+    in_x.init(a.r.xl, w.g, w.lane, R32, q_first, -kTpDelay / kQ);
+    in_g.init(a.r.gt, w.g, w.lane, R32, q_first);
+  } else {
+    in_x.init(xin_ring, w.g, w.lane, R32, q_first);
+  }
+  Out<float> o_ring;
+  o_ring.init(a.r.od, w.g, w.lane, R32);
+  const float tp_ceiling = P.tp.ceiling_linear;
+  const bool comp_on = (P.flags & kFlagCompressor) != 0;
+  double out_sq = 0.0;
+  float out_peak = 0.0f, nonfinite = 0.0f;
+  const int cb = P.control_block;
+  BlockStats *stats = a.stats;
+  int in_block = 0;
+  int64_t b = 0;
   auto block_end = [&]() {
     if (w.valid && stats) {
       BlockStats &row = stats[b * w.NS + w.s];
       row.output_square_sum = out_sq;
       row.output_sample_peak = out_peak;
       row.non_finite_output = nonfinite != 0.0f ? 1u : 0u;
-      row.tp_limiter_input_peak = tp_in_peak;
-      row.tp_limiter_gr_db = kLim && tp_gmin < 1.0f ? -20.0f * log10f(fmaxf(tp_gmin, 1e-10f)) : 0.0f;
-      row.tp_limited_events = tp_limited != 0.0f ? 1u : 0u;
     }
     out_sq = 0.0;
     out_peak = 0.0f;
     nonfinite = 0.0f;
-    tp_in_peak = 0.0f;
-    tp_gmin = 1.0f;
-    tp_limited = 0.0f;
     b += 1;
   };
-  for (int64_t t = 0; t < n; t += kU) {
-    run_steps(t, n, cb, in_block,
-              [&](int u) { step(t + u, in_x.cur[u], kLim ? in_itp.cur[u] : 0.0f, kLim ? in_tgt.cur[u] : 1.0f); }, block_end);
-    in_x.advance(t);
-    if (kLim) {
-      in_itp.advance(t);
-      in_tgt.advance(t);
-    }
-  }
-  if (w.valid) {
-    if (kLim) a.st32[(int64_t)kTpGain * w.NS + w.s] = g;
-    if (!comp_on) a.st64[(int64_t)kCompGr * w.NS + w.s] = 0.0;
-  }
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur_x)[kU] = in_x.template buf<kBuf>();
+    const float(&cur_g)[kU] = in_g.template buf<kBuf>();
+    auto step = [&](int u) {
+      float o = cur_x[u];
+      if (kLim) {
+        o = fclamp(o * cur_g[u], -tp_ceiling, tp_ceiling);
+        if (!finite_f32(o)) o = 0.0f;
+      }
+      if (finite_f32(o)) {
+        out_sq += (double)o * (double)o;
+      } else {
+        nonfinite = 1.0f;
+      }
+      out_peak = fmaxf(out_peak, fabsf(o));
+      o_ring.v[u] = o;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o_ring.store_all(qb); }, [&](int u) { o_ring.store_one(qb, u); }, block_end);
+    in_x.template refill<kBuf>(qb);
+    if (kLim) in_g.template refill<kBuf>(qb);
+  });
+  if (w.valid && !comp_on) a.st64[(int64_t)kCompGr * w.NS + w.s] = 0.0;
 }
 
 // ============================================================================================ feed-forward 6
 // output-side 4x true peak (TruePeakDetector::process_block, true_peak.rs:205-221; block_processor.rs:159) folded into the
-// block maximum, and the chain output back in stream-major order
+// block maximum, and the chain output back in stream-major order.  Tiles of 64 steps at absolute multiples of 64.
 __global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) {
   __shared__ float tile[kTileRows][kLanes + 1];
   const int g = blockIdx.y;
@@ -661,74 +909,89 @@ __global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) {
   const ChainParams &P = preset(a, g);
   const int wave = threadIdx.x >> 6;
   const int R32 = a.r.rows_f32;
-  const float *od = a.r.od + (int64_t)g * R32 * kLanes + w.lane;
-  const int64_t t0 = (int64_t)blockIdx.x * kTileRows;
-  const int64_t tw = t0 + wave * 16;  // first row of this wave
-  float h[kTpTaps + 15];
+  const float *od = a.r.od + (int64_t)g * R32 * kLanes;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t abs0 = ((n0 >> 6) + blockIdx.x) * kTileRows;
+  const int64_t first = abs0 + wave * 16;  // first sample of this wave
+  float h[kTpTaps + 16];                   // h[i]: sample first - 32 + i
 #pragma unroll
-  for (int i = 0; i < kTpTaps + 15; ++i) {
-    const float v = od[rrow(a.n0 + tw - (kTpTaps - 1) + i, R32)];
-    h[i] = v;
+  for (int k = 0; k < (kTpTaps + 16) / kQ; ++k) {
+    const Quad<float> x = load_quad(od + qoff(((first - kTpTaps) >> 2) + k, R32) + w.lane * kQ);
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) h[kQ * k + j] = x.v[j];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) tile[wave * 16 + k][w.lane] = h[kTpTaps - 1 + k];
+  for (int k = 0; k < 16; ++k) tile[wave * 16 + k][w.lane] = h[kTpTaps + k];
 #pragma unroll
-  for (int i = 0; i < kTpTaps + 15; ++i)
+  for (int i = 0; i < kTpTaps + 16; ++i)
     if (!finite_f32(h[i])) h[i] = 0.0f;  // the detector scrubs what it is fed (true_peak.rs:212)
   const int cb = P.control_block;
   float m = 0.0f;
-  int64_t mb = tw / cb;
+  int64_t mb = -1;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const int64_t t = tw + k;
-    if (t < a.n) {
-      const int64_t b = t / cb;
+    const int64_t n = first + k;
+    if (n >= n0 && n < n_end) {
+      const int64_t b = (n - n0) / cb;
       if (b != mb) {
-        if (w.valid && a.stats) atomicMax(reinterpret_cast<unsigned int *>(&a.stats[mb * w.NS + w.s].output_true_peak), __float_as_uint(m));
+        if (mb >= 0 && w.valid && a.stats)
+          atomicMax(reinterpret_cast<unsigned int *>(&a.stats[mb * w.NS + w.s].output_true_peak), __float_as_uint(m));
         m = 0.0f;
         mb = b;
       }
-      m = fmaxf(m, tp_observe_regs(h, k));
+      m = fmaxf(m, tp_observe_regs(h, kTpTaps + k));
     }
   }
-  if (tw < a.n && w.valid && a.stats)
+  if (mb >= 0 && w.valid && a.stats)
     atomicMax(reinterpret_cast<unsigned int *>(&a.stats[mb * w.NS + w.s].output_true_peak), __float_as_uint(m));
   __syncthreads();
 #pragma unroll 4
   for (int r = wave * 16; r < wave * 16 + 16; ++r) {
     const int s = g * kLanes + r;
-    const int64_t t = t0 + w.lane;
-    if (s < a.n_streams && t < a.n) a.out[(int64_t)s * a.stream_stride + t] = tile[w.lane][r];
+    const int64_t t = abs0 + w.lane - n0;
+    if (s < a.n_streams && t >= 0 && t < a.n) a.out[(int64_t)s * a.stream_stride + t] = tile[w.lane][r];
   }
 }
 
 }  // namespace
 
 // `flags`: the preset-0 chain flags (what the pipeline was planned for)
-hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, hipStream_t stream) {
+hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream) {
   const int groups = (a.n_streams + kLanes - 1) / kLanes;
-  const unsigned tiles = (unsigned)((a.n + kTileRows - 1) / kTileRows);
+  if (a.n <= 0) return hipSuccess;
+  const unsigned tiles = (unsigned)(((a.n0 + a.n - 1) >> 6) - (a.n0 >> 6) + 1);              // 64-step tiles that meet the window
+  const unsigned quads = (unsigned)(((a.n0 + a.n - 1) >> 2) - (a.n0 >> 2) + 1);              // quads that meet the window
+  const unsigned ff_blocks = (quads + kFfQuads - 1) / kFfQuads;
   const bool comp = (flags & kFlagCompressor) != 0;
   const float *lim_in = comp ? a.r.xc : a.r.xe;  // what the limiter (or, without one, the output stage) reads
-  if (a.n <= 0) return hipSuccess;
   switch (stage) {
-    case kStTin: hipLaunchKernelGGL(stage_tin_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
-    case kStCompA: hipLaunchKernelGGL(stage_comp_a_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF1: hipLaunchKernelGGL(stage_f1_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
+    case kStIn: hipLaunchKernelGGL(stage_in_kernel, dim3(groups), dim3(64), 0, stream, a); break;
+    case kStCompA:
+      if (cp.sidechain_highpass_enabled) hipLaunchKernelGGL(stage_comp_a_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
+      else hipLaunchKernelGGL(stage_comp_a_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
+      break;
+    case kStCompA2:
+      if (cp.sidechain_highpass_enabled) hipLaunchKernelGGL(stage_comp_a2_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
+      else hipLaunchKernelGGL(stage_comp_a2_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
+      break;
+    case kStF1: hipLaunchKernelGGL(stage_f1_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
     case kStCompC: hipLaunchKernelGGL(stage_comp_c_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF2: hipLaunchKernelGGL(stage_f2_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
-    case kStCompE: hipLaunchKernelGGL(stage_comp_e_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF3: hipLaunchKernelGGL(stage_f3_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
-    case kStF4: {
+    case kStF2: hipLaunchKernelGGL(stage_f2_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
+    case kStCompE:
+      if (cp.adaptive_release) hipLaunchKernelGGL(stage_comp_e_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
+      else hipLaunchKernelGGL(stage_comp_e_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
+      break;
+    case kStF3: hipLaunchKernelGGL(stage_f3_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
+    case kStF4:
       // W-aligned blocks that meet [n0, n0 + n): at most n / W_min + 2; a wave whose block starts past the window returns
       hipLaunchKernelGGL(stage_f4_kernel, dim3((unsigned)(a.n / (a.w_min > 0 ? a.w_min : 1) + 2), groups), dim3(64), 0, stream, a, lim_in);
       break;
-    }
     case kStLim: hipLaunchKernelGGL(stage_lim_kernel, dim3(groups), dim3(64), 0, stream, a); break;
     case kStF5: hipLaunchKernelGGL(stage_f5_kernel, dim3(tiles, groups), dim3(256), 0, stream, a, lim_in); break;
-    case kStTp:
-      if (flags & kFlagLimiter) hipLaunchKernelGGL(stage_tp_kernel<true>, dim3(groups), dim3(64), 0, stream, a, lim_in);
-      else hipLaunchKernelGGL(stage_tp_kernel<false>, dim3(groups), dim3(64), 0, stream, a, lim_in);
+    case kStTp: hipLaunchKernelGGL(stage_tp_kernel, dim3(groups), dim3(64), 0, stream, a); break;
+    case kStOut:
+      if (flags & kFlagLimiter) hipLaunchKernelGGL(stage_out_kernel<true>, dim3(groups), dim3(64), 0, stream, a, lim_in);
+      else hipLaunchKernelGGL(stage_out_kernel<false>, dim3(groups), dim3(64), 0, stream, a, lim_in);
       break;
     case kStF6: hipLaunchKernelGGL(stage_f6_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
     default: return hipErrorInvalidValue;

@@ -22,12 +22,18 @@ def core():
     return mic_eq_core
 
 
+LEGACY_BANDS = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]
+
+
 def run(core, kernel, audio, settings, calls, bands=TYPED_BANDS, fs=48_000.0):
     eng = core.Engine(fs, audio.shape[0])
     try:
         settings = dict(settings)
-        settings["eq_bands_v2"] = bands  # typed bands: no coefficient crossfade opens the stream
-        core.configure_auto_eq_chain(eng, fs, S.LIMITER_BANDS, settings)
+        if len(bands[0]) == 3:  # the reference's (frequency, gain, q) setters: a 72-sample coefficient crossfade opens the stream
+            core.configure_auto_eq_chain(eng, fs, bands, settings)
+        else:
+            settings["eq_bands_v2"] = bands  # typed bands: no crossfade
+            core.configure_auto_eq_chain(eng, fs, S.LIMITER_BANDS, settings)
         eng.set_kernel(kernel)
         ys, rows = [], []
         for lo, hi in calls:
@@ -79,6 +85,21 @@ def test_stage_pipeline_equals_token_ring(core, case):
     calls = ((0, 31_007), (31_007, 31_007 + 480 * 77), (31_007 + 480 * 77, n))
     want = run(core, ref_kernel, audio, settings, calls)
     got = run(core, _lib.KERNEL_STAGED, audio, settings, calls)
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("first_call", [31_007, 50, 72, 73, 5000])
+def test_coefficient_crossfade_at_the_start(core, first_call):
+    """The legacy band setters schedule a 72-sample crossfade per section (biquad.rs:263-327): the EQ stage runs its
+    two-filter form while one is pending, also when the first call ends inside it."""
+    from mic_eq_mi import _lib
+
+    settings = dict(S.limiter_settings(2.0))
+    audio = S.batch_signal(70, 70) * np.float32(1.6)
+    n = audio.shape[1]
+    calls = ((0, first_call), (first_call, n))
+    want = run(core, _lib.KERNEL_PHASED, audio, settings, calls, bands=LEGACY_BANDS)
+    got = run(core, _lib.KERNEL_STAGED, audio, settings, calls, bands=LEGACY_BANDS)
     assert_same(got, want)
 
 

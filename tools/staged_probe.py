@@ -31,7 +31,9 @@ for streams in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 el
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             eng.process_device(x.data_ptr(), y.data_ptr(), n, n, _lib.LAYOUT_STREAM_MAJOR, hs)
+            t_enq = (time.perf_counter() - t0) * 1e3
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
-        print(f"{streams:5d} streams x {seconds:g} s, {name:6s}: " + " ".join(f"{t:8.2f}" for t in times) + " ms", flush=True)
+            times.append(-t_enq)
+        print(f"{streams:5d} streams x {seconds:g} s, {name:6s}: " + " ".join((f"{t:8.2f}" if t >= 0 else f"(enqueue {-t:.2f})") for t in times) + " ms", flush=True)
         eng.close()
