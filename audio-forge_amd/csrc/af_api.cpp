@@ -832,8 +832,18 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_
         AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, st));
         AF_HIP(hipStreamSynchronize(st));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
       }
+      hipEvent_t t0 = nullptr, t1 = nullptr;
+      if (e->timing) {  // the pipeline's longest stage: its launches are what af_engine_last_chain_launch_ms reports
+        AF_HIP(hipEventCreate(&t0));
+        AF_HIP(hipEventCreate(&t1));
+        AF_HIP(hipEventRecord(t0, st));
+      }
       AF_HIP(af::launch_eq_systolic(e->d_params_eq, nullptr, e->d_st64, in_audio, nullptr, sp.rings.xe, sp.rings.xi, sp.rings.rows_f32, n0_abs,
                                     nullptr, crossfade, n, stride, e->n_streams, st));
+      if (e->timing) {
+        AF_HIP(hipEventRecord(t1, st));
+        e->chain_ms_events.push_back({t0, t1});
+      }
     } else {
       AF_HIP(af::launch_stage(k, a, run.flags, run.comp, st));
     }

@@ -8,7 +8,7 @@ falls back to a CPU implementation.
 from __future__ import annotations
 
 from . import _lib
-from ._lib import KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD, LAYOUT_STREAM_MAJOR, LAYOUT_TIME_MAJOR
+from ._lib import KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD, KERNEL_STAGED, LAYOUT_STREAM_MAJOR, LAYOUT_TIME_MAJOR
 
 _CORE_IMPORT_ERROR = None
 try:
@@ -51,4 +51,4 @@ new_noise_suppression_engine = (getattr(_core_module, "new_noise_suppression_eng
                                 if _core_module is not None else _missing_core)
 
 __all__ = ["CORE_AVAILABLE", "Engine", "NoiseSuppressor", "NoiseModel", "new_noise_suppression_engine", *_OPERATORS, "LAYOUT_STREAM_MAJOR", "LAYOUT_TIME_MAJOR", "KERNEL_AUTO",
-           "KERNEL_LANE_PER_STREAM", "KERNEL_PHASED", "KERNEL_QUAD"]
+           "KERNEL_LANE_PER_STREAM", "KERNEL_PHASED", "KERNEL_QUAD", "KERNEL_STAGED"]

@@ -378,7 +378,8 @@ def main() -> None:
     used = int(engine._lib.af_engine_last_kernel(engine._h))
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
     quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
-    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>"}.get(used, "?")
+    kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>",
+                   4: "eq_systolic_kernel (longest stage of the stage pipeline)"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on the stream it runs on)
         # (with the suppressor on the chain runs once per window, so a step holds several launches)
@@ -394,7 +395,9 @@ def main() -> None:
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1000.0, "launches_per_step": launches,
             "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
-            "limiting_resource": "vector issue on the chain's CUs (serial recurrences: one 16-wave workgroup per 64 streams per CU)",
+            "limiting_resource": ("vector issue on the chain's CUs (serial recurrences: one 16-wave workgroup per 64 streams per CU)" if used != 4 else
+                                  "dependent-instruction latency of one wave per recurrence (~8 cycles per vector instruction, "
+                                  "tools/probe/valu_latency.hip) and the hand-over between the stage queues"),
         }
         prof = profile_counters(full, streams, args.seconds)
         if prof is not None:
