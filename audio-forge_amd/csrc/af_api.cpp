@@ -661,6 +661,7 @@ int stage_stream(int k) {
     case af::kStF2: return af::kStCompE;
     case af::kStF3: case af::kStF4: return af::kStLim;
     case af::kStF5: return af::kStTp;
+    case af::kStFR: return af::kStRel;
     default: return k;
   }
 }
@@ -696,7 +697,7 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   };
   af::StageRings &r = sp.rings;
   for (float **p : {&r.xi, &r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.gt, &r.od}) AF_HIP(ring32(p));
-  for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.tg, &r.g})
+  for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.fast_r, &r.slow_r, &r.tgt_ms, &r.tg, &r.g})
     AF_HIP(ring64(p));
   sp.tw_max = tw_max;
   const int cb = e->host_params.control_block;
@@ -733,7 +734,7 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   const int64_t groups = (e->n_streams + 63) / 64;
   af::StageRings &r = sp.rings;
   for (float *p : {r.xi, r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.gt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
-  for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.tg, r.g})
+  for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.fast_r, r.slow_r, r.tgt_ms, r.tg, r.g})
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
   sp.windows = 0;
   return AF_OK;
@@ -753,8 +754,13 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_
   add(af::kStEq, -1);
   add(af::kStIn, af::kStEq);
   int last = af::kStEq;
+  const bool adaptive = comp && run.comp.adaptive_release != 0;
   if (comp) {
     for (int k : {af::kStCompA, af::kStCompA2, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE, af::kStF3}) { add(k, last); last = k; }
+    if (adaptive) {  // a side branch: the release-time meter feeds no other stage
+      add(af::kStFR, af::kStCompE);
+      add(af::kStRel, af::kStFR);
+    }
   }
   if (lim) {
     for (int k : {af::kStF4, af::kStLim, af::kStF5}) { add(k, last); last = k; }
@@ -772,7 +778,8 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_
       case af::kStF1: return af::kStF2;
       case af::kStCompC: return af::kStF2;
       case af::kStF2: return af::kStCompE;
-      case af::kStCompE: return af::kStF3;
+      case af::kStCompE: return af::kStF3;  // (with adaptive release also FR, which runs no later than F3's successor: same depth)
+      case af::kStFR: return af::kStRel;
       case af::kStF3: *f32 = true; return lim ? af::kStF5 : af::kStOut;
       case af::kStF4: return af::kStLim;
       case af::kStLim: return af::kStF5;
@@ -813,8 +820,11 @@ int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_
     const int consumer = last_consumer(k, &f32);
     const int64_t depth = std::min<int64_t>(f32 ? d32 : d64, af_engine::StagePipe::kMkSets - 1);
     static const bool no_gate = std::getenv("AF_STAGE_NOGATE") != nullptr;  // timing experiments only (unsafe)
-    if (!no_gate && consumer >= 0 && w - depth >= 0)
+    if (!no_gate && consumer >= 0 && w - depth >= 0) {
       AF_HIP(hipStreamWaitEvent(st, sp.done[consumer][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
+      if (k == af::kStCompE && adaptive)  // its envelope rings have a second reader
+        AF_HIP(hipStreamWaitEvent(st, sp.done[af::kStFR][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
+    }
     if (k == af::kStEq) {
       // the section parameters this window's EQ reads (a coefficient crossfade moves them from window to window): uploaded
       // in stream order, behind the previous window's EQ launch
@@ -862,7 +872,8 @@ int stage_pipe_join(af_engine *e, const af::ChainParams &run, hipStream_t stream
   const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
   for (int k = 0; k < af::kStCount; ++k) {
     const bool is_comp = k >= af::kStCompA && k <= af::kStF3, is_lim = k >= af::kStF4 && k <= af::kStTp;
-    if ((is_comp && !comp) || (is_lim && !lim)) continue;  // (the EQ, input-statistics, output and detector stages always run)
+    const bool is_meter = k == af::kStFR || k == af::kStRel;
+    if ((is_comp && !comp) || (is_lim && !lim) || (is_meter && !(comp && run.comp.adaptive_release))) continue;  // (the EQ, input-statistics, output and detector stages always run)
     AF_HIP(hipStreamWaitEvent(stream, sp.done[k][slot], 0));
   }
   return AF_OK;

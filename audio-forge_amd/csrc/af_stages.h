@@ -22,6 +22,7 @@ struct StageRings {
   double *peak_db;                               // log-domain peak envelope
   double *target;                                // static gain-reduction target (dB)
   double *gr;                                    // smoothed gain reduction (dB)
+  double *fast_r, *slow_r, *tgt_ms;              // adaptive release only: the envelopes each step found, the release time they ask for
   float *xc;                                     // limiter input (compressor output)
   float *sfx;                                    // suffix maxima of |xc| inside lookahead-aligned blocks
   double *tg;                                    // limiter target gain
@@ -60,6 +61,8 @@ enum StageId : int {
   kStF2,       // blended detector level -> gain-reduction target
   kStCompE,    // serial: release meter + gain-reduction smoothing, makeup gain per block
   kStF3,       // apply gain
+  kStFR,       // adaptive release: target release time from the envelopes
+  kStRel,      // serial, adaptive release: release-time smoothing (feeds no other stage)
   kStF4,       // limiter: sliding maximum over the lookahead window -> target gain
   kStLim,      // serial: limiter gain
   kStF5,       // limiter output, input-side 4x true peak, true-peak target gain

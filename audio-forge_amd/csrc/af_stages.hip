@@ -483,8 +483,12 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
   const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
   Ahead<double> in;
   in.init(a.r.target, w.g, w.lane, a.r.rows_f64, q_first);
-  Out<double> o;
+  Out<double> o, o_fast, o_slow;
   o.init(a.r.gr, w.g, w.lane, a.r.rows_f64);
+  if (kAdaptive) {  // what the release-time meter (stages FR + Rel) reads: the envelopes as each step found them
+    o_fast.init(a.r.fast_r, w.g, w.lane, a.r.rows_f64);
+    o_slow.init(a.r.slow_r, w.g, w.lane, a.r.rows_f64);
+  }
   double gr = a.st64[(int64_t)kCompGr * w.NS + w.sc], fast = a.st64[(int64_t)kCompFastEnv * w.NS + w.sc];
   double slow = a.st64[(int64_t)kCompSlowEnv * w.NS + w.sc];
   double cur_ms = a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.sc], tgt_ms = a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.sc];
@@ -495,7 +499,6 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
   const double base_release_ms = cp.base_release_ms, release_smoothing_coeff = cp.release_smoothing_coeff;
   const double attack_coeff = cp.attack_coeff, fast_release_coeff = cp.fast_release_coeff, slow_charge_coeff = cp.slow_charge_coeff;
   const double slow_release_coeff = cp.slow_release_coeff, makeup_smoothing_coeff = cp.makeup_smoothing_coeff, makeup_gain_db = cp.makeup_gain_db;
-  const double sample_rate = cp.sample_rate;
   double *mk = a.mk;
   BlockStats *stats = a.stats;
   int in_block = 0;
@@ -525,14 +528,11 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
     auto step = [&](int u) {
       const double tg = cur[u];
       if (kAdaptive) {
-        const double sustained = dclamp(div_known(slow, 6.0, 1.0 / 6.0), 0.0, 1.0);
-        const double transient_bias = dclamp(div_known(fast - slow, 7.0, 1.0 / 7.0), 0.0, 1.0);
-        const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
-        tgt_ms = 50.0 + syllabic * (400.0 - 50.0);
+        // update_adaptive_release_time_meter (compressor.rs:452-466) feeds nothing in this loop: it runs as stages FR + Rel
+        o_fast.v[u] = fast;
+        o_slow.v[u] = slow;
       } else {
         tgt_ms = base_release_ms;
-      }
-      {
         const double smoothed = release_smoothing_coeff * cur_ms + one_m_smooth * tgt_ms;
         cur_ms = fabs(tgt_ms - cur_ms) > 1.0 ? smoothed : tgt_ms;
       }
@@ -554,20 +554,85 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
       }
       o.v[u] = gr;
     };
-    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o.store_all(qb); }, [&](int u) { o.store_one(qb, u); }, block_end);
+    run_block<true>(
+        qb, n0, n, cb, in_block, step,
+        [&] {
+          o.store_all(qb);
+          if (kAdaptive) {
+            o_fast.store_all(qb);
+            o_slow.store_all(qb);
+          }
+        },
+        [&](int u) {
+          o.store_one(qb, u);
+          if (kAdaptive) {
+            o_fast.store_one(qb, u);
+            o_slow.store_one(qb, u);
+          }
+        },
+        block_end);
     in.template refill<kBuf>(qb);
   });
   if (w.valid) {
     a.st64[(int64_t)kCompGr * w.NS + w.s] = gr;
     a.st64[(int64_t)kCompFastEnv * w.NS + w.s] = fast;
     a.st64[(int64_t)kCompSlowEnv * w.NS + w.s] = slow;
+    if (!kAdaptive) {
+      a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.s] = cur_ms;
+      a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.s] = tgt_ms;
+    }
+    a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
+  }
+}
+
+// release-time meter, adaptive release only (compressor.rs:452-466,752-761): the target release time is a function of the
+// envelopes each step found (wide stage FR), its smoothing a recurrence of five instructions (serial stage Rel)
+__global__ __launch_bounds__(256) void stage_fr_kernel(StageArgs a) {
+  const int g = blockIdx.y;
+  const int R = a.r.rows_f64;
+  const int64_t gb = (int64_t)g * R * kLanes;
+  const int i = threadIdx.x;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const int64_t row = gb + e.idx;
+    const double fast = a.r.fast_r[row], slow = a.r.slow_r[row];
+    const double sustained = dclamp(div_known(slow, 6.0, 1.0 / 6.0), 0.0, 1.0);
+    const double transient_bias = dclamp(div_known(fast - slow, 7.0, 1.0 / 7.0), 0.0, 1.0);
+    const double syllabic = dclamp(sustained * sustained * (1.0 - 0.35 * transient_bias), 0.0, 1.0);
+    a.r.tgt_ms[row] = 50.0 + syllabic * (400.0 - 50.0);
+  }
+}
+
+__global__ __launch_bounds__(64) void stage_rel_kernel(StageArgs a) {
+  const Who w = who(a, blockIdx.x);
+  const ChainParams &P = preset(a, w.g);
+  const CompressorParams &cp = P.comp;
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<double> in;
+  in.init(a.r.tgt_ms, w.g, w.lane, a.r.rows_f64, q_first);
+  double cur_ms = a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.sc], tgt_ms = a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.sc];
+  const double release_smoothing_coeff = cp.release_smoothing_coeff, sample_rate = cp.sample_rate;
+  const double one_m_smooth = 1.0 - release_smoothing_coeff;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      tgt_ms = cur[u];
+      const double smoothed = release_smoothing_coeff * cur_ms + one_m_smooth * tgt_ms;
+      cur_ms = fabs(tgt_ms - cur_ms) > 1.0 ? smoothed : tgt_ms;
+    };
+    run_block<false>(qb, n0, n, 0, dummy, step, [] {}, [](int) {}, [] {});
+    in.template refill<kBuf>(qb);
+  });
+  if (w.valid) {
     a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.s] = cur_ms;
     a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.s] = tgt_ms;
-    a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
-    if (kAdaptive) {
-      const double tau = fmax(cur_ms, 0.001) / 1000.0;  // compressor.rs:760-761
-      a.st64[(int64_t)kCompReleaseCoeff * w.NS + w.s] = exp(-1.0 / (tau * sample_rate));
-    }
+    const double tau = fmax(cur_ms, 0.001) / 1000.0;  // compressor.rs:760-761
+    a.st64[(int64_t)kCompReleaseCoeff * w.NS + w.s] = exp(-1.0 / (tau * sample_rate));
   }
 }
 
@@ -981,6 +1046,8 @@ hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const Com
       if (cp.adaptive_release) hipLaunchKernelGGL(stage_comp_e_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
       else hipLaunchKernelGGL(stage_comp_e_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
       break;
+    case kStFR: hipLaunchKernelGGL(stage_fr_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
+    case kStRel: hipLaunchKernelGGL(stage_rel_kernel, dim3(groups), dim3(64), 0, stream, a); break;
     case kStF3: hipLaunchKernelGGL(stage_f3_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
     case kStF4:
       // W-aligned blocks that meet [n0, n0 + n): at most n / W_min + 2; a wave whose block starts past the window returns

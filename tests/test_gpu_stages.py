@@ -58,7 +58,7 @@ def assert_same(a, b):
 CASES = {
     "full dynamics": {},
     "no side-chain filter": {"compressor_sidechain_highpass_enabled": False},
-    "fixed release": {"compressor_adaptive_release": False},
+    "adaptive release": {"compressor_adaptive_release": True},
     "compressor only": {"limiter_enabled": False},
     "limiter only": {"compressor_enabled": False},
     "neither": {"compressor_enabled": False, "limiter_enabled": False},
