@@ -1426,6 +1426,18 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     e->trace_frames = frames;
   }
+  if (e->pipe.active) {
+    // (sized for the longest window any call can be cut into, not for this call's)
+    int64_t longest = std::max<int64_t>(unit, (window_frames / unit) * unit);
+    for (int64_t nf : win_nf) longest = std::max(longest, nf);
+    if (int rc = stage_pipe_prepare(e, std::max<int64_t>(longest * af::kRnnFrame, e->pipe.tw_max))) return rc;
+    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {  // (everything but the EQ sections is read from here)
+      e->uploaded = run;
+      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->uploaded_valid = true;
+    }
+  }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
     e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = stream;
     e->borrowed_streams = true;
@@ -1590,6 +1602,22 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     // one-launch form of the token-ring kernel and no coefficient crossfade is running
     af::ChainParams run_w = run;
     bool eq_offloaded = false;
+    if (e->pipe.active && !diag_skip_chain) {
+      // ---- the window's chain as a pipeline of stage kernels (af_stages.hip; small and medium batches): its EQ stage reads the
+      // window's overlap-add output, its last stage writes the chain output over it
+      af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
+      const hipStream_t es = e->pipe.streams[af::kStEq];
+      AF_HIP(hipStreamWaitEvent(es, syn_done[w], 0));
+      AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
+      e->last_kernel_used = AF_KERNEL_STAGED;
+      if (int rc2 = stage_pipe_window(e, run, out + seg0, out + seg0, seg_n, stream_stride, e->samples_processed + seg0, rows_w, nullptr))
+        return rc2;
+      advance_crossfades(e, seg_n);
+      run = e->host_params;  // crossfade bookkeeping may have moved on
+      if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
+      blocks_done += (seg_n + cb - 1) / cb;
+      continue;
+    }
     if (eq_offload && !diag_skip_chain) {
       const int n_presets = 1 + (int)e->extra_presets.size();
       bool ok = true;
@@ -1661,6 +1689,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
   }
+  if (e->pipe.active)
+    if (int rc = stage_pipe_join(e, run, stream)) return rc;
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
   return AF_OK;
