@@ -150,3 +150,53 @@ def test_unsupported_configurations_are_refused(core):
             eng.process(S.batch_signal(2, 2))
     finally:
         eng.close()
+
+
+def test_randomized_configurations_against_the_other_kernels(core):
+    """Seeded random chain settings, batch shapes and call patterns: the stage pipeline against kernel 2 (kernel 3 where the
+    lookahead does not fit kernel 2's LDS layout), bit for bit.  What a hand-picked list of cases would miss."""
+    from mic_eq_mi import _lib
+
+    rng = np.random.default_rng(20261004)
+    kinds = ("bell", "low_shelf", "high_shelf", "high_pass", "low_pass", "notch")
+    for case in range(14):
+        fs = float(rng.choice([44_100.0, 48_000.0, 48_000.0, 96_000.0]))
+        n_streams = int(rng.choice([1, 3, 64, 65, 130]))
+        blocks = int(rng.integers(8, 60))
+        audio = (S.batch_signal(n_streams, blocks) * np.float32(rng.uniform(0.3, 2.5))).astype(np.float32)
+        n = audio.shape[1]
+        bands = []
+        for i in range(10):
+            kind = kinds[int(rng.integers(0, len(kinds)))]
+            slope = int(rng.choice([12, 12, 24])) if kind in ("high_pass", "low_pass") else 12
+            bands.append((kind, float(60.0 * 1.8**i * rng.uniform(0.8, 1.2)), float(rng.uniform(-9.0, 9.0)), float(rng.uniform(0.5, 3.0)), slope,
+                          bool(rng.random() > 0.15)))
+        lookahead = float(rng.choice([0.25, 0.5, 1.0, 2.0, 2.0, 3.0]))
+        settings = dict(S.limiter_settings(lookahead))
+        settings.update({
+            "compressor_enabled": bool(rng.random() > 0.2),
+            "compressor_threshold_db": float(rng.uniform(-40.0, -8.0)),
+            "compressor_ratio": float(rng.uniform(1.5, 10.0)),
+            "compressor_attack_ms": float(rng.uniform(0.5, 40.0)),
+            "compressor_release_ms": float(rng.uniform(20.0, 500.0)),
+            "compressor_makeup_gain_db": float(rng.uniform(0.0, 9.0)),
+            "compressor_adaptive_release": bool(rng.random() > 0.5),
+            "compressor_sidechain_highpass_enabled": bool(rng.random() > 0.3),
+            "limiter_enabled": bool(rng.random() > 0.2),
+            "limiter_ceiling_db": float(rng.uniform(-6.0, -0.1)),
+            "limiter_release_ms": float(rng.uniform(10.0, 200.0)),
+        })
+        cuts = sorted(set(int(v) for v in rng.integers(1, n, size=int(rng.integers(0, 4)))))
+        edges = [0, *cuts, n]
+        calls = list(zip(edges[:-1], edges[1:]))
+        lookahead_samples = round(lookahead * fs / 1000.0)
+        ref_kernel = _lib.KERNEL_PHASED if lookahead_samples <= 120 else _lib.KERNEL_QUAD
+        use_legacy = bool(rng.random() > 0.6)
+        legacy = [(b[1], b[2], b[3]) for b in bands]
+        kw = dict(bands=legacy if use_legacy else bands, fs=fs)
+        want = run(core, ref_kernel, audio, settings, calls, **kw)
+        got = run(core, _lib.KERNEL_STAGED, audio, settings, calls, **kw)
+        try:
+            assert_same(got, want)
+        except AssertionError as err:
+            raise AssertionError(f"case {case}: fs {fs}, {n_streams} streams, calls {calls}, settings {settings}: {err}") from None
