@@ -170,6 +170,8 @@ struct af_engine {
     static constexpr int kMkSets = 16;
     double *d_mk = nullptr;
     int64_t mk_rows = 0;                   // rows (blocks x streams) per set
+    int64_t call_stride = 0;               // stream stride of the call being scheduled (one-launch-per-step form)
+    bool diagonal = true;                  // one launch per step (AF_STAGE_DIAGONAL=0: a queue per stage, events between them)
   } pipe;
   int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
@@ -680,7 +682,9 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   }
   const int64_t groups = (e->n_streams + 63) / 64;
   const int64_t hist = 2 * (af::kMaxLookahead + 1) + 64;
-  const size_t r64 = pow2_at_least(5 * tw_max + hist), r32 = pow2_at_least(12 * tw_max + hist);
+  // a ring holds the windows between its producer and its last consumer, one more, and the history: with one launch per step the
+  // stages advance in lock step (two resp. seven windows apart at most); with a queue per stage a producer may run ahead
+  const size_t r64 = pow2_at_least((sp.diagonal ? 4 : 5) * tw_max + hist), r32 = pow2_at_least((sp.diagonal ? 10 : 12) * tw_max + hist);
   sp.rings.rows_f64 = (int32_t)r64;
   sp.rings.rows_f32 = (int32_t)r32;
   auto ring32 = [&](float **p) -> hipError_t {
@@ -705,7 +709,7 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   if (sp.d_mk) (void)hipFree(sp.d_mk);
   AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
   for (int k = 0; k < af::kStCount; ++k) {
-    if (!sp.streams[k] && stage_stream(k) == k) {
+    if (!sp.streams[k] && stage_stream(k) == k && (!sp.diagonal || k == af::kStEq)) {
       // the serial stages are what the pipeline waits for: their queues go first
       const bool serial = k == af::kStEq || k == af::kStCompA || k == af::kStCompA2 || k == af::kStOut || k == af::kStCompC || k == af::kStCompE || k == af::kStLim || k == af::kStTp;
       // a queue of its own per stage (streams created the plain way share a few hardware queues, and kernels of one
@@ -737,6 +741,94 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.fast_r, r.slow_r, r.tgt_ms, r.tg, r.g})
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
   sp.windows = 0;
+  return AF_OK;
+}
+
+// ---- the pipeline as one launch per step (af_stages.h, DiagArgs): launch j runs stage k on window j - skew(k) -----------------
+// The stages of this configuration in chain order, each one launch step behind the stage it reads from.
+struct StagePlan {
+  int stage[af::kStCount], skew[af::kStCount], n = 0;
+  int depth = 0;  // the last stage's skew: launches a window needs to leave the pipeline after it entered
+};
+StagePlan stage_plan(const af::ChainParams &run) {
+  StagePlan p;
+  const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
+  auto add = [&](int k, int sk) { p.stage[p.n] = k; p.skew[p.n] = sk; ++p.n; p.depth = std::max(p.depth, sk); return sk; };
+  int at = add(af::kStEq, 0);
+  add(af::kStIn, 1);
+  if (comp) {
+    for (int k : {af::kStCompA, af::kStCompA2, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE}) at = add(k, at + 1);
+    if (run.comp.adaptive_release) {
+      add(af::kStFR, at + 1);
+      add(af::kStRel, at + 2);
+    }
+    at = add(af::kStF3, at + 1);
+  }
+  if (lim)
+    for (int k : {af::kStF4, af::kStLim, af::kStF5, af::kStTp}) at = add(k, at + 1);
+  at = add(af::kStOut, at + 1);
+  add(af::kStF6, at + 1);
+  return p;
+}
+
+// launch step j of a call whose windows are `wins`: every stage whose window exists
+int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &plan, const std::vector<af::DiagWin> &wins, int64_t j,
+                    hipStream_t stream) {
+  auto &sp = e->pipe;
+  af::DiagArgs d{};
+  d.base.params = e->d_params;
+  d.base.group_preset = nullptr;
+  d.base.st64 = e->d_st64;
+  d.base.st32 = e->d_st32;
+  d.base.n_streams = e->n_streams;
+  d.base.w_min = run.lim.lookahead_samples + 1;
+  d.base.r = sp.rings;
+  d.params_eq = e->d_params_eq;
+  d.flags = run.flags;
+  d.sidechain = run.comp.sidechain_highpass_enabled;
+  d.adaptive = run.comp.adaptive_release;
+  d.base.stream_stride = sp.call_stride;
+  // two dispatches per step: the one-wave workgroups (serial stages and F4), then the wide stages
+  for (int pass = 0; pass < 2; ++pass) {
+    unsigned blocks = 0;
+    d.n_roles = 0;
+    for (int i = 0; i < plan.n; ++i) {
+      const int k = plan.stage[i];
+      const bool wide = k == af::kStF1 || k == af::kStF2 || k == af::kStFR || k == af::kStF3 || k == af::kStF5 || k == af::kStF6;
+      if (wide != (pass == 1)) continue;
+      const int64_t wi = j - plan.skew[i];
+      if (wi < 0 || wi >= (int64_t)wins.size()) continue;
+      af::DiagRole &role = d.roles[d.n_roles++];
+      role.stage = k;
+      role.win = wins[(size_t)wi];
+      unsigned gy = 1;
+      role.gx = af::stage_role_blocks(k, role.win.n0, role.win.n, e->n_streams, d.base.w_min, &gy);
+      role.first_block = blocks;
+      blocks += role.gx * gy;
+    }
+    if (d.n_roles == 0) continue;
+    AF_HIP(af::launch_stage_diag(d, blocks, pass == 1, stream));
+    e->last_launches += 1;
+  }
+  return AF_OK;
+}
+
+// the EQ stage's parameter block for the window about to enter the pipeline (stream-ordered behind the previous window's launch)
+int stage_diag_eq_params(af_engine *e, const af::ChainParams &run, hipStream_t stream, bool *crossfade) {
+  *crossfade = false;
+  for (int k = 0; k < run.n_eq_sections; ++k) *crossfade |= run.eq[k].xf_remaining > 0;
+  if (!e->d_params_eq || e->eq_params_presets != 1) {
+    if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
+    e->d_params_eq = nullptr;
+    AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams)));
+    e->eq_params_presets = 1;
+    e->uploaded_eq.clear();
+  }
+  if (e->uploaded_eq.size() != 1 || std::memcmp(e->uploaded_eq.data(), &run, sizeof run) != 0) {
+    e->uploaded_eq.assign(1, run);
+    AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, stream));
+    AF_HIP(hipStreamSynchronize(stream));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
+  }
   return AF_OK;
 }
 
@@ -1294,6 +1386,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
+    {
+      const char *env = std::getenv("AF_STAGE_DIAGONAL");
+      e->pipe.diagonal = !env || std::atoi(env) != 0;
+    }
     if (e->pipe.active)
       if (int rc = stage_pipe_clear(e)) return rc;
   }
@@ -1301,7 +1397,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     // ---- the chain as a pipeline of stage kernels over windows of whole control blocks (af_stages.hip)
     // windows of ~0.2 s: with 4800-sample windows the queues' hand-overs cost as much as the kernels (59 ms per 10 s at 256
     // streams), with 9600 49 ms, with 19200 the pipeline's fill time takes the gain back (49 ms)
-    int64_t tw = (int64_t)cb * std::max<int64_t>(1, (e->n_streams <= 1024 ? 9600 : 4800) / cb);
+    // (one launch per step: a launch costs ~10 us, the pipeline's fill is depth x window time: short windows)
+    int64_t tw = (int64_t)cb * std::max<int64_t>(1, (e->pipe.diagonal ? 2880 : (e->n_streams <= 1024 ? 9600 : 4800)) / cb);
     if (const char *env = std::getenv("AF_STAGE_WINDOW")) tw = (int64_t)cb * std::max<int64_t>(1, std::atoll(env) / cb);
     if (int rc = stage_pipe_prepare(e, std::max<int64_t>(tw, e->pipe.tw_max))) return rc;
     {
@@ -1314,6 +1411,43 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       }
     }
     e->last_kernel_used = AF_KERNEL_STAGED;
+    if (e->pipe.diagonal) {
+      // one launch per step on the caller's stream: launch j runs every stage on the window it has reached
+      const StagePlan plan = stage_plan(e->host_params);
+      std::vector<af::DiagWin> wins;
+      int64_t blocks_at = 0;
+      for (int64_t t0 = 0; t0 < n_samples; t0 += tw) {
+        const int64_t n_w = std::min<int64_t>(tw, n_samples - t0);
+        af::DiagWin wd{};
+        wd.n0 = e->samples_processed + t0;
+        wd.n = n_w;
+        wd.stats = e->d_stats + blocks_at * e->n_streams;
+        wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
+        wd.in = in + t0;
+        wd.out = out + t0;
+        wins.push_back(wd);
+        blocks_at += (n_w + cb - 1) / cb;
+      }
+      e->pipe.call_stride = stream_stride;
+      AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
+      const int64_t steps = (int64_t)wins.size() + plan.depth;
+      for (int64_t j = 0; j < steps; ++j) {
+        if (j < (int64_t)wins.size()) {  // window j enters: its EQ stage reads the section parameters as they stand now
+          bool crossfade = false;
+          if (int rc = stage_diag_eq_params(e, e->host_params, stream, &crossfade)) return rc;
+          wins[(size_t)j].eq_crossfade = crossfade ? 1 : 0;
+          advance_crossfades(e, wins[(size_t)j].n);
+        }
+        if (int rc = stage_diag_step(e, e->uploaded, plan, wins, j, stream)) return rc;
+      }
+      e->pipe.windows += (int64_t)wins.size();
+      if (e->timing) {
+        AF_HIP(hipEventRecord(e->ev_mid, stream));
+        AF_HIP(hipEventRecord(e->ev_stop, stream));
+      }
+      e->samples_processed += n_samples;
+      return AF_OK;
+    }
     hipEvent_t ev_in;
     if (int rc = engine_event(e, &ev_in)) return rc;
     AF_HIP(hipEventRecord(ev_in, stream));
@@ -1491,6 +1625,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   const hipStream_t fin = split_synthesis ? e->fin_stream : nullptr;
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
   int64_t blocks_done = 0;
+  std::vector<af::DiagWin> diag_wins;                 // the call's windows in the stage pipeline (one launch per step)
+  const StagePlan diag_plan = stage_plan(run);
   static const bool eq_offload_env = [] {  // AF_EQ_OFFLOAD=0: the EQ stays inside the chain launches (A/B runs)
     const char *env = std::getenv("AF_EQ_OFFLOAD");
     return !env || std::atoi(env) != 0;
@@ -1602,6 +1738,32 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     // one-launch form of the token-ring kernel and no coefficient crossfade is running
     af::ChainParams run_w = run;
     bool eq_offloaded = false;
+    if (e->pipe.active && e->pipe.diagonal && !diag_skip_chain) {
+      // ---- the window's chain as one more step of the stage pipeline (af_stages.hip; small and medium batches): this window
+      // enters (its EQ stage reads the overlap-add output), the windows before it move one stage on
+      const hipStream_t ds = e->pipe.streams[af::kStEq];
+      af::DiagWin wd{};
+      wd.n0 = e->samples_processed + seg0;
+      wd.n = seg_n;
+      wd.stats = e->d_stats + blocks_done * e->n_streams;
+      wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
+      wd.in = out + seg0;
+      wd.out = out + seg0;
+      AF_HIP(hipStreamWaitEvent(ds, syn_done[w], 0));
+      AF_HIP(hipMemsetAsync(wd.stats, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
+      bool crossfade = false;
+      if (int rc2 = stage_diag_eq_params(e, run, ds, &crossfade)) return rc2;
+      wd.eq_crossfade = crossfade ? 1 : 0;
+      diag_wins.push_back(wd);
+      e->last_kernel_used = AF_KERNEL_STAGED;
+      e->pipe.call_stride = stream_stride;
+      if (int rc2 = stage_diag_step(e, run, diag_plan, diag_wins, (int64_t)diag_wins.size() - 1, ds)) return rc2;
+      advance_crossfades(e, seg_n);
+      run = e->host_params;  // crossfade bookkeeping may have moved on
+      if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
+      blocks_done += (seg_n + cb - 1) / cb;
+      continue;
+    }
     if (e->pipe.active && !diag_skip_chain) {
       // ---- the window's chain as a pipeline of stage kernels (af_stages.hip; small and medium batches): its EQ stage reads the
       // window's overlap-add output, its last stage writes the chain output over it
@@ -1689,8 +1851,18 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
   }
-  if (e->pipe.active)
+  if (e->pipe.active && e->pipe.diagonal && !diag_wins.empty()) {
+    const hipStream_t ds = e->pipe.streams[af::kStEq];
+    for (int64_t j = (int64_t)diag_wins.size(); j < (int64_t)diag_wins.size() + diag_plan.depth; ++j)  // the pipeline empties
+      if (int rc = stage_diag_step(e, run, diag_plan, diag_wins, j, ds)) return rc;
+    e->pipe.windows += (int64_t)diag_wins.size();
+    hipEvent_t ev;
+    if (int rc = next_event(&ev)) return rc;
+    AF_HIP(hipEventRecord(ev, ds));
+    AF_HIP(hipStreamWaitEvent(stream, ev, 0));
+  } else if (e->pipe.active) {
     if (int rc = stage_pipe_join(e, run, stream)) return rc;
+  }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;
   return AF_OK;

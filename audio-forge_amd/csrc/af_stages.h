@@ -72,6 +72,38 @@ enum StageId : int {
   kStCount
 };
 
+// ---- one launch for a whole diagonal of the (stage, window) grid ---------------------------------------------------------
+// Launch step j runs stage k on window j - skew(k) for every stage at once (roles of a dispatch, picked by block index; two
+// dispatches per step: one-wave workgroups for the serial stages, four-wave ones for the wide stages); a stage's inputs were
+// written by earlier steps, so stream order is all the synchronisation there is.
+struct DiagWin {               // what differs from window to window
+  int64_t n0, n;
+  BlockStats *stats;
+  double *mk;
+  const float *in;
+  float *out;
+  int32_t eq_slot;             // which of the EQ parameter blocks this window's EQ stage reads
+  int32_t eq_crossfade;        // a coefficient crossfade is pending in that block
+};
+struct DiagRole {
+  int32_t stage;               // StageId
+  uint32_t first_block, gx;    // blocks [first_block, next role's first_block): block b -> (bx, by) = ((b - first) % gx, (b - first) / gx)
+  DiagWin win;
+};
+struct DiagArgs {
+  StageArgs base;              // everything that is the same for all windows (rings, state planes, parameter block)
+  const ChainParams *params_eq;  // [kEqParamSlots] parameter blocks of the EQ stage
+  DiagRole roles[kStCount];
+  int32_t n_roles;
+  uint32_t flags;              // chain flags the pipeline was planned for
+  int32_t sidechain, adaptive; // compressor switches (they pick code paths)
+};
+constexpr int kEqParamSlots = 4;
+// `wide`: the roles are the wide stages F1, F2, FR, F3, F5, F6 (workgroups of four waves); else all the others (one wave)
+hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream);
+// blocks a role needs for a window: `gx` (the launch uses gx * gy blocks, gy = groups except for the EQ stage)
+unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, int32_t w_min, unsigned *gy);
+
 // `flags`, `cp`: the chain flags and compressor switches the pipeline was planned for (they pick kernel variants)
 hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream);
 

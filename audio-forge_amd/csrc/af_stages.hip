@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "af_dsp.h"
+#include "af_eq_systolic_body.h"
 #include "af_stages.h"
 
 namespace af {
@@ -210,8 +211,8 @@ __device__ __forceinline__ Elem ff_elem(const StageArgs &a, int64_t q, int i, in
 // ============================================================================================ block input statistics
 // input_square_sum (f64, in sample order) and input_sample_peak of every control block (block_processor.rs:111-118) from
 // the scrubbed input the EQ kernel leaves in the `xi` ring: two instructions on the recurrence, off the EQ's own loop
-__global__ __launch_bounds__(64) void stage_in_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_in_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const int64_t n = a.n, n0 = a.n0;
   const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(64) void stage_in_kernel(StageArgs a) {
 // about a dozen instructions per step each: (1) the high-pass, the low band's envelope and the presence signal, (2) the
 // voiced, presence and rms envelopes
 template <bool kSc>
-__global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_comp_a_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
@@ -316,8 +317,8 @@ __global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) {
 }
 
 template <bool kSc>
-__global__ __launch_bounds__(64) void stage_comp_a2_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_comp_a2_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
@@ -382,8 +383,8 @@ __global__ __launch_bounds__(64) void stage_comp_a2_kernel(StageArgs a) {
 
 // ============================================================================================ feed-forward 1
 // detector weight, instantaneous peak and RMS levels in dB (update_sidechain_band_metrics, compressor.rs:438-449)
-__global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) {
-  const int g = blockIdx.y;
+__device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
   const ChainParams &P = preset(a, g);
   const CompressorParams cp = P.comp;  // by value: fields read through the pointer would be re-loaded after every store
   const int R = a.r.rows_f64;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) {
   const int i = threadIdx.x, lane = i >> 2;
   const int s = g * kLanes + lane;
   const int64_t NS = a.n_streams;
-  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) {
 
 // ============================================================================================ compressor, serial part C
 // log-domain peak envelope (compressor.rs:735-742)
-__global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_comp_c_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
@@ -454,14 +455,14 @@ __global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) {
 
 // ============================================================================================ feed-forward 2
 // blended detector level -> static gain-reduction target (compressor.rs:744-750,657-678)
-__global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) {
-  const int g = blockIdx.y;
+__device__ __forceinline__ void stage_f2_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
   const ChainParams &P = preset(a, g);
   const CompressorParams cp = P.comp;
   const int R = a.r.rows_f64;
   const int64_t gb = (int64_t)g * R * kLanes;
   const int i = threadIdx.x;
-  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
@@ -474,8 +475,8 @@ __global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) {
 // ============================================================================================ compressor, serial part E
 // release-time meter + gain-reduction smoothing, makeup gain per control block (compressor.rs:452-505,604-617,752-764)
 template <bool kAdaptive>
-__global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   __builtin_amdgcn_s_setprio(3);
@@ -587,12 +588,12 @@ __global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) {
 
 // release-time meter, adaptive release only (compressor.rs:452-466,752-761): the target release time is a function of the
 // envelopes each step found (wide stage FR), its smoothing a recurrence of five instructions (serial stage Rel)
-__global__ __launch_bounds__(256) void stage_fr_kernel(StageArgs a) {
-  const int g = blockIdx.y;
+__device__ __forceinline__ void stage_fr_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
   const int R = a.r.rows_f64;
   const int64_t gb = (int64_t)g * R * kLanes;
   const int i = threadIdx.x;
-  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
@@ -605,8 +606,8 @@ __global__ __launch_bounds__(256) void stage_fr_kernel(StageArgs a) {
   }
 }
 
-__global__ __launch_bounds__(64) void stage_rel_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_rel_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
   const int64_t n = a.n, n0 = a.n0;
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(64) void stage_rel_kernel(StageArgs a) {
 
 // ============================================================================================ feed-forward 3
 // apply gain (compressor.rs:771-773)
-__global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) {
-  const int g = blockIdx.y;
+__device__ __forceinline__ void stage_f3_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
   const ChainParams &P = preset(a, g);
   const int R = a.r.rows_f64, R32 = a.r.rows_f32;
   const int64_t gb = (int64_t)g * R * kLanes, gb32 = (int64_t)g * R32 * kLanes;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) {
   const int sc = s < a.n_streams ? s : a.n_streams - 1;
   const int64_t NS = a.n_streams;
   const int cb = P.control_block;
-  const int64_t q0 = (a.n0 >> 2) + (int64_t)blockIdx.x * kFfQuads;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
@@ -663,8 +664,8 @@ __global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) {
 // lookahead limiter, the part without memory (limiter.rs:246-270): the maximum of |x| over the last W = lookahead + 1
 // samples, from suffix maxima of the previous W-aligned block and the running prefix maximum of the current one (the
 // maximum is exact whatever the grouping), and the gain it asks for.  One wave per (block that meets the window, group).
-__global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *xin_ring) {
-  const int g = blockIdx.y;
+__device__ __forceinline__ void stage_f4_body(const StageArgs &a, const float *xin_ring, int bx, int by) {
+  const int g = by;
   const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
   const int W = P.lim.lookahead_samples + 1;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *
   const int lane = w.lane;
   const int64_t n0 = a.n0, n_end = a.n0 + a.n;
   // blocks are aligned to absolute multiples of W
-  const int64_t B = n0 / W + blockIdx.x;
+  const int64_t B = n0 / W + bx;
   const int64_t b0 = B * W;
   if (b0 >= n_end) return;
   // suffix maxima of block B - 1, eight loads at a time
@@ -733,8 +734,8 @@ __global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *
 
 // ============================================================================================ limiter, serial part
 // gain smoothing (limiter.rs:271-284)
-__global__ __launch_bounds__(64) void stage_lim_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_lim_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
   const int64_t n = a.n, n0 = a.n0;
@@ -790,9 +791,9 @@ __device__ __forceinline__ float tp_observe_regs(const float (&h)[kN], int i) {
   return peak;
 }
 
-__global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float *xin_ring) {
+__device__ __forceinline__ void stage_f5_body(const StageArgs &a, const float *xin_ring, int bx, int by) {
   __shared__ float xl_t[kTileRows + kTpTaps][kLanes];
-  const int g = blockIdx.y;
+  const int g = by;
   const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
   const int wave = threadIdx.x >> 6;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float 
   const double ceil_lin = P.lim.ceiling_linear;
   const float tp_ceiling = P.tp.ceiling_linear;
   const int64_t n0 = a.n0, n_end = a.n0 + a.n;
-  const int64_t abs0 = ((n0 >> 6) + blockIdx.x) * kTileRows;  // first sample of the tile
+  const int64_t abs0 = ((n0 >> 6) + bx) * kTileRows;  // first sample of the tile
   // samples abs0 - 32 .. abs0 + 63 of the limiter output (before the stream's first sample the rings hold zeros)
   for (int i = wave; i < kTileRows + kTpTaps; i += 4) {
     const int64_t n = abs0 - kTpTaps + i;
@@ -848,8 +849,8 @@ __global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float 
 // ============================================================================================ true-peak limiter, serial parts
 // (1) the gain (true_peak.rs:353-374) and the limiter's own block figures; (2) the chain output and the block output
 // statistics (block_processor.rs:150-170), whose square sum is a recurrence of its own
-__global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_tp_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
   const int R32 = a.r.rows_f32;
@@ -902,8 +903,8 @@ __global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a) {
 }
 
 template <bool kLim>
-__global__ __launch_bounds__(64) void stage_out_kernel(StageArgs a, const float *xin_ring) {
-  const Who w = who(a, blockIdx.x);
+__device__ __forceinline__ void stage_out_body(const StageArgs &a, const float *xin_ring, int bx, int by) {
+  const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
   const int R32 = a.r.rows_f32;
@@ -967,16 +968,16 @@ __global__ __launch_bounds__(64) void stage_out_kernel(StageArgs a, const float 
 // ============================================================================================ feed-forward 6
 // output-side 4x true peak (TruePeakDetector::process_block, true_peak.rs:205-221; block_processor.rs:159) folded into the
 // block maximum, and the chain output back in stream-major order.  Tiles of 64 steps at absolute multiples of 64.
-__global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) {
+__device__ __forceinline__ void stage_f6_body(const StageArgs &a, int bx, int by) {
   __shared__ float tile[kTileRows][kLanes + 1];
-  const int g = blockIdx.y;
+  const int g = by;
   const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
   const int wave = threadIdx.x >> 6;
   const int R32 = a.r.rows_f32;
   const float *od = a.r.od + (int64_t)g * R32 * kLanes;
   const int64_t n0 = a.n0, n_end = a.n0 + a.n;
-  const int64_t abs0 = ((n0 >> 6) + blockIdx.x) * kTileRows;
+  const int64_t abs0 = ((n0 >> 6) + bx) * kTileRows;
   const int64_t first = abs0 + wave * 16;  // first sample of this wave
   float h[kTpTaps + 16];                   // h[i]: sample first - 32 + i
 #pragma unroll
@@ -1018,7 +1019,139 @@ __global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) {
   }
 }
 
+
+// ---- every stage as a kernel of its own (one queue per stage, events between them) ...
+__global__ __launch_bounds__(64) void stage_in_kernel(StageArgs a) { stage_in_body(a, blockIdx.x, blockIdx.y); }
+template <bool kSc>
+__global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) { stage_comp_a_body<kSc>(a, blockIdx.x, blockIdx.y); }
+template <bool kSc>
+__global__ __launch_bounds__(64) void stage_comp_a2_kernel(StageArgs a) { stage_comp_a2_body<kSc>(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) { stage_f1_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) { stage_comp_c_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) { stage_f2_body(a, blockIdx.x, blockIdx.y); }
+template <bool kAdaptive>
+__global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) { stage_comp_e_body<kAdaptive>(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_fr_kernel(StageArgs a) { stage_fr_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void stage_rel_kernel(StageArgs a) { stage_rel_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) { stage_f3_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *xin_ring) { stage_f4_body(a, xin_ring, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void stage_lim_kernel(StageArgs a) { stage_lim_body(a, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float *xin_ring) { stage_f5_body(a, xin_ring, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a) { stage_tp_body(a, blockIdx.x, blockIdx.y); }
+template <bool kLim>
+__global__ __launch_bounds__(64) void stage_out_kernel(StageArgs a, const float *xin_ring) { stage_out_body<kLim>(a, xin_ring, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) { stage_f6_body(a, blockIdx.x, blockIdx.y); }
+
+
+// ---- ... or all stages of one launch step as roles of TWO dispatches (DiagArgs, af_stages.h): the serial stages (and the
+// one-wave-per-block wide one) in workgroups of one wave, the wide stages in workgroups of four.  Nothing but stream order
+// between launches, no queue per stage.  (One dispatch for both kinds costs the wide stages their occupancy: the serial
+// stages' ~250 registers per lane become every workgroup's: 4096 streams 330 ms per 10 s.)
+struct RolePick {
+  int bx, by;
+  int r;
+};
+__device__ __forceinline__ RolePick pick_role(const DiagArgs &d) {
+  const uint32_t b = blockIdx.x;
+  int r = 0;
+  for (int i = 1; i < d.n_roles; ++i)
+    if (b >= d.roles[i].first_block) r = i;  // (uniform)
+  const uint32_t local = b - d.roles[r].first_block;
+  return RolePick{(int)(local % d.roles[r].gx), (int)(local / d.roles[r].gx), r};
+}
+__device__ __forceinline__ StageArgs role_args(const DiagArgs &d, const DiagRole &role) {
+  StageArgs a = d.base;
+  a.n0 = role.win.n0;
+  a.n = role.win.n;
+  a.stats = role.win.stats;
+  a.mk = role.win.mk;
+  a.in = role.win.in;
+  a.out = role.win.out;
+  return a;
+}
+
+__global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
+  const RolePick pk = pick_role(d);
+  const DiagRole &role = d.roles[pk.r];
+  const StageArgs a = role_args(d, role);
+  const int bx = pk.bx, by = pk.by;
+  const bool comp = (d.flags & kFlagCompressor) != 0, lim = (d.flags & kFlagLimiter) != 0;
+  const float *lim_in = comp ? a.r.xc : a.r.xe;
+  switch (role.stage) {
+    case kStEq: {
+      EqSystolicArgs ea{d.params_eq + role.win.eq_slot, nullptr, a.st64, a.in, nullptr, a.r.xe, a.r.xi, nullptr,
+                        a.n, a.stream_stride, a.n0, a.n_streams, a.r.rows_f32};
+      if (role.win.eq_crossfade) eq_systolic_body<false, true>(ea, bx);
+      else eq_systolic_body<false, false>(ea, bx);
+      break;
+    }
+    case kStIn: stage_in_body(a, bx, by); break;
+    case kStCompA:
+      if (d.sidechain) stage_comp_a_body<true>(a, bx, by);
+      else stage_comp_a_body<false>(a, bx, by);
+      break;
+    case kStCompA2:
+      if (d.sidechain) stage_comp_a2_body<true>(a, bx, by);
+      else stage_comp_a2_body<false>(a, bx, by);
+      break;
+    case kStCompC: stage_comp_c_body(a, bx, by); break;
+    case kStCompE:
+      if (d.adaptive) stage_comp_e_body<true>(a, bx, by);
+      else stage_comp_e_body<false>(a, bx, by);
+      break;
+    case kStRel: stage_rel_body(a, bx, by); break;
+    case kStF4: stage_f4_body(a, lim_in, bx, by); break;
+    case kStLim: stage_lim_body(a, bx, by); break;
+    case kStTp: stage_tp_body(a, bx, by); break;
+    case kStOut:
+      if (lim) stage_out_body<true>(a, lim_in, bx, by);
+      else stage_out_body<false>(a, lim_in, bx, by);
+      break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(256) void stage_diag_wide_kernel(DiagArgs d) {
+  const RolePick pk = pick_role(d);
+  const DiagRole &role = d.roles[pk.r];
+  const StageArgs a = role_args(d, role);
+  const int bx = pk.bx, by = pk.by;
+  const bool comp = (d.flags & kFlagCompressor) != 0;
+  const float *lim_in = comp ? a.r.xc : a.r.xe;
+  switch (role.stage) {
+    case kStF1: stage_f1_body(a, bx, by); break;
+    case kStF2: stage_f2_body(a, bx, by); break;
+    case kStFR: stage_fr_body(a, bx, by); break;
+    case kStF3: stage_f3_body(a, bx, by); break;
+    case kStF5: stage_f5_body(a, lim_in, bx, by); break;
+    case kStF6: stage_f6_body(a, bx, by); break;
+    default: break;
+  }
+}
+
 }  // namespace
+
+
+unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, int32_t w_min, unsigned *gy) {
+  const unsigned groups = (unsigned)((n_streams + kLanes - 1) / kLanes);
+  const unsigned tiles = (unsigned)(((n0 + n - 1) >> 6) - (n0 >> 6) + 1);
+  const unsigned quads = (unsigned)(((n0 + n - 1) >> 2) - (n0 >> 2) + 1);
+  *gy = groups;
+  switch (stage) {
+    case kStEq: *gy = 1; return (unsigned)((n_streams + 3) / 4);  // four streams per wave
+    case kStF1: case kStF2: case kStF3: case kStFR: return (quads + kFfQuads - 1) / kFfQuads;
+    case kStF4: return (unsigned)(n / (w_min > 0 ? w_min : 1) + 2);
+    case kStF5: case kStF6: return tiles;
+    default: *gy = 1; return groups;  // serial stages: one workgroup (its first wave) per group
+  }
+}
+
+hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream) {
+  if (total_blocks == 0) return hipSuccess;
+  if (wide) hipLaunchKernelGGL(stage_diag_wide_kernel, dim3(total_blocks), dim3(256), 0, stream, d);
+  else hipLaunchKernelGGL(stage_diag_serial_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
+  return hipGetLastError();
+}
 
 // `flags`: the preset-0 chain flags (what the pipeline was planned for)
 hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream) {
