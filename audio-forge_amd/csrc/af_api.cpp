@@ -163,15 +163,12 @@ struct af_engine {
     af::StageRings rings{};
     std::vector<void *> allocs;
     int64_t tw_max = 0;                    // longest window the rings were sized for
-    hipStream_t streams[af::kStCount] = {};
-    static constexpr int kEventRing = 32;
-    hipEvent_t done[af::kStCount][kEventRing] = {};
+    hipStream_t stream = nullptr;          // where the launch steps go when the suppressor's pipeline feeds the chain
     int64_t windows = 0;                   // windows launched since the rings were last cleared
-    static constexpr int kMkSets = 16;
+    static constexpr int kMkSets = 4;
     double *d_mk = nullptr;
     int64_t mk_rows = 0;                   // rows (blocks x streams) per set
-    int64_t call_stride = 0;               // stream stride of the call being scheduled (one-launch-per-step form)
-    bool diagonal = true;                  // one launch per step (AF_STAGE_DIAGONAL=0: a queue per stage, events between them)
+    int64_t call_stride = 0;               // stream stride of the call being scheduled
   } pipe;
   int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
@@ -655,20 +652,7 @@ size_t pow2_at_least(int64_t n) {
   return p;
 }
 
-// A feed-forward stage shares the stream of the serial stage it feeds (it has to finish before that one starts anyway):
-// ten queues instead of fifteen, and an event less per pair.
-int stage_stream(int k) {
-  switch (k) {
-    case af::kStF1: return af::kStCompC;
-    case af::kStF2: return af::kStCompE;
-    case af::kStF3: case af::kStF4: return af::kStLim;
-    case af::kStF5: return af::kStTp;
-    case af::kStFR: return af::kStRel;
-    default: return k;
-  }
-}
-
-// rings sized for windows of up to `tw_max` samples, the streams and the events
+// rings sized for windows of up to `tw_max` samples
 int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   auto &sp = e->pipe;
   if (sp.rings.xe && tw_max <= sp.tw_max) return AF_OK;
@@ -682,9 +666,9 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   }
   const int64_t groups = (e->n_streams + 63) / 64;
   const int64_t hist = 2 * (af::kMaxLookahead + 1) + 64;
-  // a ring holds the windows between its producer and its last consumer, one more, and the history: with one launch per step the
-  // stages advance in lock step (two resp. seven windows apart at most); with a queue per stage a producer may run ahead
-  const size_t r64 = pow2_at_least((sp.diagonal ? 4 : 5) * tw_max + hist), r32 = pow2_at_least((sp.diagonal ? 10 : 12) * tw_max + hist);
+  // a ring holds the windows between its producer and its last consumer, one more, and the history: the stages advance in lock
+  // step, an f64 ring's reader two windows behind its writer at most, the EQ output's last reader seven
+  const size_t r64 = pow2_at_least(4 * tw_max + hist), r32 = pow2_at_least(10 * tw_max + hist);
   sp.rings.rows_f64 = (int32_t)r64;
   sp.rings.rows_f32 = (int32_t)r32;
   auto ring32 = [&](float **p) -> hipError_t {
@@ -708,26 +692,15 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   sp.mk_rows = ((tw_max + cb - 1) / cb + 1) * e->n_streams;
   if (sp.d_mk) (void)hipFree(sp.d_mk);
   AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
-  for (int k = 0; k < af::kStCount; ++k) {
-    if (!sp.streams[k] && stage_stream(k) == k && (!sp.diagonal || k == af::kStEq)) {
-      // the serial stages are what the pipeline waits for: their queues go first
-      const bool serial = k == af::kStEq || k == af::kStCompA || k == af::kStCompA2 || k == af::kStOut || k == af::kStCompC || k == af::kStCompE || k == af::kStLim || k == af::kStTp;
-      // a queue of its own per stage (streams created the plain way share a few hardware queues, and kernels of one
-      // queue run in order: the stages would not overlap): a CU-masked stream with every CU enabled
-      hipDeviceProp_t prop;
-      AF_HIP(hipGetDeviceProperties(&prop, e->device));
-      std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
-      for (int bit = 0; bit < prop.multiProcessorCount; ++bit) mask[bit >> 5] |= 1u << (bit & 31);
-      static const bool plain_streams = std::getenv("AF_STAGE_PLAIN_STREAMS") != nullptr;  // timing experiments
-      if (plain_streams || hipExtStreamCreateWithCUMask(&sp.streams[k], (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        (void)hipGetLastError();
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        AF_HIP(hipStreamCreateWithPriority(&sp.streams[k], hipStreamNonBlocking, serial ? hi : lo));
-      }
+  if (!sp.stream) {  // (a queue of its own: a CU-masked stream with every CU enabled; plain streams share a few hardware queues)
+    hipDeviceProp_t prop;
+    AF_HIP(hipGetDeviceProperties(&prop, e->device));
+    std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
+    for (int bit = 0; bit < prop.multiProcessorCount; ++bit) mask[bit >> 5] |= 1u << (bit & 31);
+    if (hipExtStreamCreateWithCUMask(&sp.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      AF_HIP(hipStreamCreateWithFlags(&sp.stream, hipStreamNonBlocking));
     }
-    for (int i = 0; i < af_engine::StagePipe::kEventRing; ++i)
-      if (!sp.done[k][i]) AF_HIP(hipEventCreateWithFlags(&sp.done[k][i], hipEventDisableTiming));
   }
   return AF_OK;
 }
@@ -807,7 +780,17 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
       blocks += role.gx * gy;
     }
     if (d.n_roles == 0) continue;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (e->timing && pass == 0) {  // the serial stages' dispatch is what a step lasts: what af_engine_last_chain_launch_ms reports
+      AF_HIP(hipEventCreate(&t0));
+      AF_HIP(hipEventCreate(&t1));
+      AF_HIP(hipEventRecord(t0, stream));
+    }
     AF_HIP(af::launch_stage_diag(d, blocks, pass == 1, stream));
+    if (t0) {
+      AF_HIP(hipEventRecord(t1, stream));
+      e->chain_ms_events.push_back({t0, t1});
+    }
     e->last_launches += 1;
   }
   return AF_OK;
@@ -828,145 +811,6 @@ int stage_diag_eq_params(af_engine *e, const af::ChainParams &run, hipStream_t s
     e->uploaded_eq.assign(1, run);
     AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, stream));
     AF_HIP(hipStreamSynchronize(stream));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
-  }
-  return AF_OK;
-}
-
-// One window through the stage kernels.  `in_audio`: the window's stream-major input, valid once `ready` has fired; `out`
-// receives the chain output (it may be `in_audio`: the EQ stage has read a window before its last stage writes it).
-// Every stage runs on its own stream: behind the stage it reads from (this window), behind itself of the previous window
-// (stream order), and behind the consumers of the ring rows it is about to overwrite.
-int stage_pipe_window(af_engine *e, const af::ChainParams &run, const float *in_audio, float *out, int64_t n, int64_t stride,
-                      int64_t n0_abs, af::BlockStats *stats, hipEvent_t ready) {
-  auto &sp = e->pipe;
-  const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
-  // the stage list of this configuration, each with the stage it reads from
-  int order[af::kStCount], pred[af::kStCount], n_order = 0;
-  auto add = [&](int k, int from) { order[n_order] = k; pred[n_order] = from; ++n_order; };
-  add(af::kStEq, -1);
-  add(af::kStIn, af::kStEq);
-  int last = af::kStEq;
-  const bool adaptive = comp && run.comp.adaptive_release != 0;
-  if (comp) {
-    for (int k : {af::kStCompA, af::kStCompA2, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE, af::kStF3}) { add(k, last); last = k; }
-    if (adaptive) {  // a side branch: the release-time meter feeds no other stage
-      add(af::kStFR, af::kStCompE);
-      add(af::kStRel, af::kStFR);
-    }
-  }
-  if (lim) {
-    for (int k : {af::kStF4, af::kStLim, af::kStF5}) { add(k, last); last = k; }
-  }
-  if (lim) { add(af::kStTp, last); last = af::kStTp; }
-  add(af::kStOut, last);
-  add(af::kStF6, af::kStOut);
-  // who reads last what a stage writes, and in which kind of ring
-  auto last_consumer = [&](int k, bool *f32) -> int {
-    *f32 = false;
-    switch (k) {
-      case af::kStEq: *f32 = true; return comp ? af::kStF3 : (lim ? af::kStF5 : af::kStOut);  // xe (xi: the input statistics, sooner)
-      case af::kStCompA: return af::kStF1;
-      case af::kStCompA2: return af::kStF1;
-      case af::kStF1: return af::kStF2;
-      case af::kStCompC: return af::kStF2;
-      case af::kStF2: return af::kStCompE;
-      case af::kStCompE: return af::kStF3;  // (with adaptive release also FR, which runs no later than F3's successor: same depth)
-      case af::kStFR: return af::kStRel;
-      case af::kStF3: *f32 = true; return lim ? af::kStF5 : af::kStOut;
-      case af::kStF4: return af::kStLim;
-      case af::kStLim: return af::kStF5;
-      case af::kStF5: *f32 = true; return af::kStOut;
-      case af::kStTp: *f32 = true; return af::kStOut;
-      case af::kStOut: *f32 = true; return af::kStF6;
-      default: return -1;
-    }
-  };
-  const int64_t w = sp.windows;
-  const int slot = (int)(w % af_engine::StagePipe::kEventRing);
-  const int64_t d64 = std::min<int64_t>(sp.rings.rows_f64 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
-  const int64_t d32 = std::min<int64_t>(sp.rings.rows_f32 / sp.tw_max - 2, af_engine::StagePipe::kEventRing - 2);
-  af::StageArgs a{};
-  a.params = e->d_params;
-  a.group_preset = nullptr;
-  a.st64 = e->d_st64;
-  a.st32 = e->d_st32;
-  a.stats = stats;
-  a.mk = sp.d_mk + (w % af_engine::StagePipe::kMkSets) * sp.mk_rows;
-  a.in = in_audio;
-  a.out = out;
-  a.stream_stride = stride;
-  a.n = n;
-  a.n0 = n0_abs;
-  a.n_streams = e->n_streams;
-  a.w_min = run.lim.lookahead_samples + 1;
-  a.r = sp.rings;
-  for (int i = 0; i < n_order; ++i) {
-    const int k = order[i];
-    const hipStream_t st = sp.streams[stage_stream(k)];
-    if (pred[i] < 0) {
-      if (ready) AF_HIP(hipStreamWaitEvent(st, ready, 0));
-    } else if (stage_stream(pred[i]) != stage_stream(k)) {
-      AF_HIP(hipStreamWaitEvent(st, sp.done[pred[i]][slot], 0));
-    }
-    bool f32 = false;
-    const int consumer = last_consumer(k, &f32);
-    const int64_t depth = std::min<int64_t>(f32 ? d32 : d64, af_engine::StagePipe::kMkSets - 1);
-    static const bool no_gate = std::getenv("AF_STAGE_NOGATE") != nullptr;  // timing experiments only (unsafe)
-    if (!no_gate && consumer >= 0 && w - depth >= 0) {
-      AF_HIP(hipStreamWaitEvent(st, sp.done[consumer][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
-      if (k == af::kStCompE && adaptive)  // its envelope rings have a second reader
-        AF_HIP(hipStreamWaitEvent(st, sp.done[af::kStFR][(int)((w - depth) % af_engine::StagePipe::kEventRing)], 0));
-    }
-    if (k == af::kStEq) {
-      // the section parameters this window's EQ reads (a coefficient crossfade moves them from window to window): uploaded
-      // in stream order, behind the previous window's EQ launch
-      bool crossfade = false;
-      for (int j = 0; j < run.n_eq_sections; ++j) crossfade |= run.eq[j].xf_remaining > 0;
-      if (!e->d_params_eq || e->eq_params_presets != 1) {
-        if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
-        e->d_params_eq = nullptr;
-        AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams)));
-        e->eq_params_presets = 1;
-        e->uploaded_eq.clear();
-      }
-      if (e->uploaded_eq.size() != 1 || std::memcmp(e->uploaded_eq.data(), &run, sizeof run) != 0) {
-        e->uploaded_eq.assign(1, run);
-        AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, st));
-        AF_HIP(hipStreamSynchronize(st));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
-      }
-      hipEvent_t t0 = nullptr, t1 = nullptr;
-      if (e->timing) {  // the pipeline's longest stage: its launches are what af_engine_last_chain_launch_ms reports
-        AF_HIP(hipEventCreate(&t0));
-        AF_HIP(hipEventCreate(&t1));
-        AF_HIP(hipEventRecord(t0, st));
-      }
-      AF_HIP(af::launch_eq_systolic(e->d_params_eq, nullptr, e->d_st64, in_audio, nullptr, sp.rings.xe, sp.rings.xi, sp.rings.rows_f32, n0_abs,
-                                    nullptr, crossfade, n, stride, e->n_streams, st));
-      if (e->timing) {
-        AF_HIP(hipEventRecord(t1, st));
-        e->chain_ms_events.push_back({t0, t1});
-      }
-    } else {
-      AF_HIP(af::launch_stage(k, a, run.flags, run.comp, st));
-    }
-    AF_HIP(hipEventRecord(sp.done[k][slot], st));
-    e->last_launches += 1;
-  }
-  sp.windows += 1;
-  return AF_OK;
-}
-
-// the caller's stream waits for everything the pipeline has in flight
-int stage_pipe_join(af_engine *e, const af::ChainParams &run, hipStream_t stream) {
-  auto &sp = e->pipe;
-  if (sp.windows == 0) return AF_OK;
-  const int slot = (int)((sp.windows - 1) % af_engine::StagePipe::kEventRing);
-  const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
-  for (int k = 0; k < af::kStCount; ++k) {
-    const bool is_comp = k >= af::kStCompA && k <= af::kStF3, is_lim = k >= af::kStF4 && k <= af::kStTp;
-    const bool is_meter = k == af::kStFR || k == af::kStRel;
-    if ((is_comp && !comp) || (is_lim && !lim) || (is_meter && !(comp && run.comp.adaptive_release))) continue;  // (the EQ, input-statistics, output and detector stages always run)
-    AF_HIP(hipStreamWaitEvent(stream, sp.done[k][slot], 0));
   }
   return AF_OK;
 }
@@ -1028,11 +872,7 @@ void af_engine_destroy(af_engine *e) {
     for (void *p : e->pipe.allocs) (void)hipFree(p);
     (void)hipFree(e->pipe.d_mk);
   }
-  for (auto &row : e->pipe.done)
-    for (hipEvent_t ev : row)
-      if (ev) (void)hipEventDestroy(ev);
-  for (hipStream_t st : e->pipe.streams)
-    if (st) (void)hipStreamDestroy(st);
+  if (e->pipe.stream) (void)hipStreamDestroy(e->pipe.stream);
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = nullptr;
@@ -1386,19 +1226,14 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
-    {
-      const char *env = std::getenv("AF_STAGE_DIAGONAL");
-      e->pipe.diagonal = !env || std::atoi(env) != 0;
-    }
     if (e->pipe.active)
       if (int rc = stage_pipe_clear(e)) return rc;
   }
   if (!e->supp.enabled && e->pipe.active) {
     // ---- the chain as a pipeline of stage kernels over windows of whole control blocks (af_stages.hip)
-    // windows of ~0.2 s: with 4800-sample windows the queues' hand-overs cost as much as the kernels (59 ms per 10 s at 256
-    // streams), with 9600 49 ms, with 19200 the pipeline's fill time takes the gain back (49 ms)
-    // (one launch per step: a launch costs ~10 us, the pipeline's fill is depth x window time: short windows)
-    int64_t tw = (int64_t)cb * std::max<int64_t>(1, (e->pipe.diagonal ? 2880 : (e->n_streams <= 1024 ? 9600 : 4800)) / cb);
+    // (a launch step costs ~20 us, the pipeline's fill is depth x window time: 960 samples 45.7 ms per 10 s at 256 streams,
+    // 1920 41.2, 2880 39.7, 4800 42.7, 9600 40.3)
+    int64_t tw = (int64_t)cb * std::max<int64_t>(1, 2880 / cb);
     if (const char *env = std::getenv("AF_STAGE_WINDOW")) tw = (int64_t)cb * std::max<int64_t>(1, std::atoll(env) / cb);
     if (int rc = stage_pipe_prepare(e, std::max<int64_t>(tw, e->pipe.tw_max))) return rc;
     {
@@ -1411,8 +1246,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       }
     }
     e->last_kernel_used = AF_KERNEL_STAGED;
-    if (e->pipe.diagonal) {
-      // one launch per step on the caller's stream: launch j runs every stage on the window it has reached
+    {
+      // one launch step per window on the caller's stream: step j runs every stage on the window it has reached
       const StagePlan plan = stage_plan(e->host_params);
       std::vector<af::DiagWin> wins;
       int64_t blocks_at = 0;
@@ -1448,31 +1283,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       e->samples_processed += n_samples;
       return AF_OK;
     }
-    hipEvent_t ev_in;
-    if (int rc = engine_event(e, &ev_in)) return rc;
-    AF_HIP(hipEventRecord(ev_in, stream));
-    int64_t blocks_done = 0;
-    for (int64_t t0 = 0; t0 < n_samples; t0 += tw) {
-      const int64_t n_w = std::min<int64_t>(tw, n_samples - t0);
-      af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
-      const int64_t blocks_w = (n_w + cb - 1) / cb;
-      // (the call's rows are cleared on the EQ stage's stream, ahead of every stage that writes into them)
-      if (t0 == 0) {
-        AF_HIP(hipStreamWaitEvent(e->pipe.streams[af::kStEq], ev_in, 0));
-        AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, e->pipe.streams[af::kStEq]));
-      }
-      if (int rc = stage_pipe_window(e, e->host_params, in + t0, out + t0, n_w, stream_stride, e->samples_processed + t0, rows_w, nullptr))
-        return rc;
-      advance_crossfades(e, n_w);
-      blocks_done += blocks_w;
-    }
-    if (int rc = stage_pipe_join(e, e->host_params, stream)) return rc;
-    if (e->timing) {
-      AF_HIP(hipEventRecord(e->ev_mid, stream));
-      AF_HIP(hipEventRecord(e->ev_stop, stream));
-    }
-    e->samples_processed += n_samples;
-    return AF_OK;
   }
   if (!e->supp.enabled) {
     int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
@@ -1738,10 +1548,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     // one-launch form of the token-ring kernel and no coefficient crossfade is running
     af::ChainParams run_w = run;
     bool eq_offloaded = false;
-    if (e->pipe.active && e->pipe.diagonal && !diag_skip_chain) {
+    if (e->pipe.active && !diag_skip_chain) {
       // ---- the window's chain as one more step of the stage pipeline (af_stages.hip; small and medium batches): this window
       // enters (its EQ stage reads the overlap-add output), the windows before it move one stage on
-      const hipStream_t ds = e->pipe.streams[af::kStEq];
+      const hipStream_t ds = e->pipe.stream;
       af::DiagWin wd{};
       wd.n0 = e->samples_processed + seg0;
       wd.n = seg_n;
@@ -1758,22 +1568,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       e->last_kernel_used = AF_KERNEL_STAGED;
       e->pipe.call_stride = stream_stride;
       if (int rc2 = stage_diag_step(e, run, diag_plan, diag_wins, (int64_t)diag_wins.size() - 1, ds)) return rc2;
-      advance_crossfades(e, seg_n);
-      run = e->host_params;  // crossfade bookkeeping may have moved on
-      if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
-      blocks_done += (seg_n + cb - 1) / cb;
-      continue;
-    }
-    if (e->pipe.active && !diag_skip_chain) {
-      // ---- the window's chain as a pipeline of stage kernels (af_stages.hip; small and medium batches): its EQ stage reads the
-      // window's overlap-add output, its last stage writes the chain output over it
-      af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
-      const hipStream_t es = e->pipe.streams[af::kStEq];
-      AF_HIP(hipStreamWaitEvent(es, syn_done[w], 0));
-      AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
-      e->last_kernel_used = AF_KERNEL_STAGED;
-      if (int rc2 = stage_pipe_window(e, run, out + seg0, out + seg0, seg_n, stream_stride, e->samples_processed + seg0, rows_w, nullptr))
-        return rc2;
       advance_crossfades(e, seg_n);
       run = e->host_params;  // crossfade bookkeeping may have moved on
       if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
@@ -1851,8 +1645,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
   }
-  if (e->pipe.active && e->pipe.diagonal && !diag_wins.empty()) {
-    const hipStream_t ds = e->pipe.streams[af::kStEq];
+  if (e->pipe.active && !diag_wins.empty()) {
+    const hipStream_t ds = e->pipe.stream;
     for (int64_t j = (int64_t)diag_wins.size(); j < (int64_t)diag_wins.size() + diag_plan.depth; ++j)  // the pipeline empties
       if (int rc = stage_diag_step(e, run, diag_plan, diag_wins, j, ds)) return rc;
     e->pipe.windows += (int64_t)diag_wins.size();
@@ -1860,8 +1654,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, ds));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
-  } else if (e->pipe.active) {
-    if (int rc = stage_pipe_join(e, run, stream)) return rc;
   }
   if (e->timing) AF_HIP(hipEventRecord(e->ev_stop, stream));
   e->samples_processed += n_samples;

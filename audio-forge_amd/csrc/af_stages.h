@@ -82,7 +82,7 @@ struct DiagWin {               // what differs from window to window
   double *mk;
   const float *in;
   float *out;
-  int32_t eq_slot;             // which of the EQ parameter blocks this window's EQ stage reads
+  int32_t eq_slot;             // index into params_eq (0)
   int32_t eq_crossfade;        // a coefficient crossfade is pending in that block
 };
 struct DiagRole {
@@ -92,19 +92,15 @@ struct DiagRole {
 };
 struct DiagArgs {
   StageArgs base;              // everything that is the same for all windows (rings, state planes, parameter block)
-  const ChainParams *params_eq;  // [kEqParamSlots] parameter blocks of the EQ stage
+  const ChainParams *params_eq;  // the parameter block the EQ stage reads (it moves from window to window while a crossfade runs)
   DiagRole roles[kStCount];
   int32_t n_roles;
   uint32_t flags;              // chain flags the pipeline was planned for
   int32_t sidechain, adaptive; // compressor switches (they pick code paths)
 };
-constexpr int kEqParamSlots = 4;
 // `wide`: the roles are the wide stages F1, F2, FR, F3, F5, F6 (workgroups of four waves); else all the others (one wave)
 hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream);
 // blocks a role needs for a window: `gx` (the launch uses gx * gy blocks, gy = groups except for the EQ stage)
 unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, int32_t w_min, unsigned *gy);
-
-// `flags`, `cp`: the chain flags and compressor switches the pipeline was planned for (they pick kernel variants)
-hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream);
 
 }  // namespace af

@@ -6,10 +6,11 @@
 // The chain is a string of short recurrences (a few dependent f64 operations per sample each) separated by feed-forward
 // math (log10 / exp10 / sqrt / divisions, two 128-tap FIRs, a sliding maximum).  Here every recurrence is a kernel of its
 // own -- one wave per 64-stream group, lane = stream, its state in REGISTERS for the whole window, nothing but the
-// recurrence in its loop -- and every feed-forward piece is a wide elementwise kernel over (sample, stream).  The kernels
-// of a window run back to back on streams of their own, so while stage k works on window w stage k+1 works on window
-// w-1: a launch set lasts as long as the SLOWEST STAGE needs per sample, not the sum, and the feed-forward work spreads
-// over the whole chip.  Hand-over between stages is through rings in HBM (af_stages.h), ~0.3 KB per sample step per
+// recurrence in its loop -- and every feed-forward piece is a wide elementwise stage over (sample, stream).  Time is cut
+// into windows; launch step j runs stage k on window j - skew(k) for all stages at once (roles of two dispatches, picked
+// by block index), so while stage k works on window w stage k+1 works on window w-1: a step lasts as long as the SLOWEST
+// STAGE needs for a window, not the sum, the wide work spreads over the whole chip, and stream order between the steps is
+// all the synchronisation there is.  Hand-over between stages is through rings in HBM (af_stages.h), ~0.3 KB per sample step per
 // stream: nothing at a few hundred streams, the reason large batches stay on the token-ring kernel.
 //
 // What bounds a serial stage (tools/probe/valu_latency.hip): a lone wave issues a dependent vector instruction every
@@ -1020,33 +1021,10 @@ __device__ __forceinline__ void stage_f6_body(const StageArgs &a, int bx, int by
 }
 
 
-// ---- every stage as a kernel of its own (one queue per stage, events between them) ...
-__global__ __launch_bounds__(64) void stage_in_kernel(StageArgs a) { stage_in_body(a, blockIdx.x, blockIdx.y); }
-template <bool kSc>
-__global__ __launch_bounds__(64) void stage_comp_a_kernel(StageArgs a) { stage_comp_a_body<kSc>(a, blockIdx.x, blockIdx.y); }
-template <bool kSc>
-__global__ __launch_bounds__(64) void stage_comp_a2_kernel(StageArgs a) { stage_comp_a2_body<kSc>(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_f1_kernel(StageArgs a) { stage_f1_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void stage_comp_c_kernel(StageArgs a) { stage_comp_c_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_f2_kernel(StageArgs a) { stage_f2_body(a, blockIdx.x, blockIdx.y); }
-template <bool kAdaptive>
-__global__ __launch_bounds__(64) void stage_comp_e_kernel(StageArgs a) { stage_comp_e_body<kAdaptive>(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_fr_kernel(StageArgs a) { stage_fr_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void stage_rel_kernel(StageArgs a) { stage_rel_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_f3_kernel(StageArgs a) { stage_f3_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void stage_f4_kernel(StageArgs a, const float *xin_ring) { stage_f4_body(a, xin_ring, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void stage_lim_kernel(StageArgs a) { stage_lim_body(a, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_f5_kernel(StageArgs a, const float *xin_ring) { stage_f5_body(a, xin_ring, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(64) void stage_tp_kernel(StageArgs a) { stage_tp_body(a, blockIdx.x, blockIdx.y); }
-template <bool kLim>
-__global__ __launch_bounds__(64) void stage_out_kernel(StageArgs a, const float *xin_ring) { stage_out_body<kLim>(a, xin_ring, blockIdx.x, blockIdx.y); }
-__global__ __launch_bounds__(256) void stage_f6_kernel(StageArgs a) { stage_f6_body(a, blockIdx.x, blockIdx.y); }
-
-
-// ---- ... or all stages of one launch step as roles of TWO dispatches (DiagArgs, af_stages.h): the serial stages (and the
-// one-wave-per-block wide one) in workgroups of one wave, the wide stages in workgroups of four.  Nothing but stream order
-// between launches, no queue per stage.  (One dispatch for both kinds costs the wide stages their occupancy: the serial
-// stages' ~250 registers per lane become every workgroup's: 4096 streams 330 ms per 10 s.)
+// ---- all stages of one launch step as roles of TWO dispatches (DiagArgs, af_stages.h): the serial stages (and the
+// one-wave-per-block wide one) in workgroups of one wave, the wide stages in workgroups of four.  (One dispatch for both kinds
+// costs the wide stages their occupancy -- the serial stages' ~250 registers per lane become every workgroup's: 256 streams
+// 36 ms per 10 s instead of 40, but 1024 streams 88 instead of 69 and 4096 streams 330 instead of 225.)
 struct RolePick {
   int bx, by;
   int r;
@@ -1150,52 +1128,6 @@ hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide
   if (total_blocks == 0) return hipSuccess;
   if (wide) hipLaunchKernelGGL(stage_diag_wide_kernel, dim3(total_blocks), dim3(256), 0, stream, d);
   else hipLaunchKernelGGL(stage_diag_serial_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
-  return hipGetLastError();
-}
-
-// `flags`: the preset-0 chain flags (what the pipeline was planned for)
-hipError_t launch_stage(int stage, const StageArgs &a, uint32_t flags, const CompressorParams &cp, hipStream_t stream) {
-  const int groups = (a.n_streams + kLanes - 1) / kLanes;
-  if (a.n <= 0) return hipSuccess;
-  const unsigned tiles = (unsigned)(((a.n0 + a.n - 1) >> 6) - (a.n0 >> 6) + 1);              // 64-step tiles that meet the window
-  const unsigned quads = (unsigned)(((a.n0 + a.n - 1) >> 2) - (a.n0 >> 2) + 1);              // quads that meet the window
-  const unsigned ff_blocks = (quads + kFfQuads - 1) / kFfQuads;
-  const bool comp = (flags & kFlagCompressor) != 0;
-  const float *lim_in = comp ? a.r.xc : a.r.xe;  // what the limiter (or, without one, the output stage) reads
-  switch (stage) {
-    case kStIn: hipLaunchKernelGGL(stage_in_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStCompA:
-      if (cp.sidechain_highpass_enabled) hipLaunchKernelGGL(stage_comp_a_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
-      else hipLaunchKernelGGL(stage_comp_a_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
-      break;
-    case kStCompA2:
-      if (cp.sidechain_highpass_enabled) hipLaunchKernelGGL(stage_comp_a2_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
-      else hipLaunchKernelGGL(stage_comp_a2_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
-      break;
-    case kStF1: hipLaunchKernelGGL(stage_f1_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
-    case kStCompC: hipLaunchKernelGGL(stage_comp_c_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF2: hipLaunchKernelGGL(stage_f2_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
-    case kStCompE:
-      if (cp.adaptive_release) hipLaunchKernelGGL(stage_comp_e_kernel<true>, dim3(groups), dim3(64), 0, stream, a);
-      else hipLaunchKernelGGL(stage_comp_e_kernel<false>, dim3(groups), dim3(64), 0, stream, a);
-      break;
-    case kStFR: hipLaunchKernelGGL(stage_fr_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
-    case kStRel: hipLaunchKernelGGL(stage_rel_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF3: hipLaunchKernelGGL(stage_f3_kernel, dim3(ff_blocks, groups), dim3(256), 0, stream, a); break;
-    case kStF4:
-      // W-aligned blocks that meet [n0, n0 + n): at most n / W_min + 2; a wave whose block starts past the window returns
-      hipLaunchKernelGGL(stage_f4_kernel, dim3((unsigned)(a.n / (a.w_min > 0 ? a.w_min : 1) + 2), groups), dim3(64), 0, stream, a, lim_in);
-      break;
-    case kStLim: hipLaunchKernelGGL(stage_lim_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStF5: hipLaunchKernelGGL(stage_f5_kernel, dim3(tiles, groups), dim3(256), 0, stream, a, lim_in); break;
-    case kStTp: hipLaunchKernelGGL(stage_tp_kernel, dim3(groups), dim3(64), 0, stream, a); break;
-    case kStOut:
-      if (flags & kFlagLimiter) hipLaunchKernelGGL(stage_out_kernel<true>, dim3(groups), dim3(64), 0, stream, a, lim_in);
-      else hipLaunchKernelGGL(stage_out_kernel<false>, dim3(groups), dim3(64), 0, stream, a, lim_in);
-      break;
-    case kStF6: hipLaunchKernelGGL(stage_f6_kernel, dim3(tiles, groups), dim3(256), 0, stream, a); break;
-    default: return hipErrorInvalidValue;
-  }
   return hipGetLastError();
 }
 

@@ -379,7 +379,7 @@ def main() -> None:
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
     quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
     kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>",
-                   4: "eq_systolic_kernel (longest stage of the stage pipeline)"}.get(used, "?")
+                   4: "stage_diag_serial_kernel (the serial stages of one launch step of the stage pipeline)"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on the stream it runs on)
         # (with the suppressor on the chain runs once per window, so a step holds several launches)
@@ -397,7 +397,7 @@ def main() -> None:
             "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES_PER_SAMPLE * frames_per_launch,
             "limiting_resource": ("vector issue on the chain's CUs (serial recurrences: one 16-wave workgroup per 64 streams per CU)" if used != 4 else
                                   "dependent-instruction latency of one wave per recurrence (~8 cycles per vector instruction, "
-                                  "tools/probe/valu_latency.hip) and the hand-over between the stage queues"),
+                                  "tools/probe/valu_latency.hip): a step lasts as long as its longest stage, the EQ"),
         }
         prof = profile_counters(full, streams, args.seconds)
         if prof is not None:
