@@ -72,18 +72,23 @@ hipError_t launch_scale_probe(const float *in, float *out, int64_t n, hipStream_
   return hipGetLastError();
 }
 
-// The pass is a chain of short per-sample recurrences (DC block, 80 Hz high-pass in f64, the model's own
-// high-pass), so its duration is samples x recurrence latency whatever the lane count: one wave takes 64
-// streams (lane = stream), keeps a whole 64-sample tile of its stream in registers so that no LDS or HBM
-// latency sits inside the recurrence, and has the next tile's 64 row loads in flight while it computes.
+// The pass is a chain of short per-sample recurrences (DC block and 80 Hz high-pass in f64; the model's own high-pass)
+// around a feed-forward soft clip, so its duration is samples x (instructions on the longest recurrence) x ~8 cycles (one
+// wave issues a dependent vector instruction every ~8 cycles: tools/probe/valu_latency.hip) whatever the lane count.  As one
+// wave doing everything that was ~800 cycles per sample (2.4-3.0 ms per 8 880-sample window at ANY batch: what a small batch
+// waited for).  Now a workgroup of six waves takes 64 streams and works as a pipeline over 64-sample tiles, one barrier per
+// tile: wave 0 loads tile i (64 row loads, transposed into LDS), wave 1 runs the front end on tile i-1 (lane = stream), wave 2
+// the soft clip on tile i-2 (lane = TIME: 64 independent samples per instruction), wave 3 the model's high-pass on tile i-3
+// (lane = stream), waves 4 and 5 write the dry signal of tile i-2 and the model input of tile i-4 back as rows.
 constexpr int kPreGroup = 64;
-constexpr int kPreChunk = 16;  // samples held in registers at a time
+constexpr int kPreWaves = 6;
+constexpr int kPreTile = 64 * (kPreGroup + 1);  // floats per LDS tile
 template <bool kClamp, bool kDcHp, bool kRaw>
-__global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
-  __shared__ float tile[64][kPreGroup + 1];
-  __shared__ float dry[64][kPreGroup + 1];
+__global__ __launch_bounds__(64 * kPreWaves) void supp_prefilter_kernel(SuppArgs a) {
+  extern __shared__ float pre_lds[];  // in[2], dry[2], sc[2], xh[2]
   constexpr bool kFront = kClamp || kDcHp;
-  const int lane = threadIdx.x;
+  float *t_in = pre_lds, *t_dry = pre_lds + 2 * kPreTile, *t_sc = pre_lds + 4 * kPreTile, *t_xh = pre_lds + 6 * kPreTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s0 = blockIdx.x * kPreGroup;
   const int s = s0 + lane;
   const bool valid = s < a.n_streams;
@@ -92,112 +97,149 @@ __global__ __launch_bounds__(64) void supp_prefilter_kernel(SuppArgs a) {
   const int64_t n = (int64_t)a.n_frames * kRnnFrame;
   const int64_t xh_stride = kPitchBuf + n;
   float *st = a.state + (int64_t)sc * SuppState::kCount;
-  float m0 = st[SuppState::kHpMem], m1 = st[SuppState::kHpMem + 1];
-  // realtime front end state (chain planes): DC block x1/y1 (f32), 80 Hz high-pass z1/z2 (f64)
-  float dc_x1 = 0.0f, dc_y1 = 0.0f;
-  double z1 = 0.0, z2 = 0.0;
-  if (kDcHp) {
-    dc_x1 = a.chain_st32[(int64_t)a.f32_dc_x1 * NS + sc];
-    dc_y1 = a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + sc];
-    z1 = a.chain_st64[(int64_t)a.f64_pre_z1 * NS + sc];
-    z2 = a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + sc];
-  }
   const int64_t ntiles = (n + 63) / 64;
-  float nxt[kPreGroup];
-  // rows are clamped, not skipped, so the 64 row loads of a tile are independent and stay in flight together
-  auto fetch = [&](int64_t t0) {
-    const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
-    const int64_t col = a.frame0 * kRnnFrame + t0 + (lane < len ? lane : len - 1);
-#pragma unroll
-    for (int r = 0; r < kPreGroup; ++r) {
-      const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
-      nxt[r] = a.in[(int64_t)sr * a.in_stride + col];
-    }
-  };
-  if (ntiles > 0) fetch(0);
+  auto at = [](float *tile, int t, int col) -> float & { return tile[t * (kPreGroup + 1) + col]; };
+  auto tile_len = [&](int64_t ti) { return (int)((n - ti * 64) < 64 ? (n - ti * 64) : 64); };
+
   // history: the previous 1728 model-input samples go in front of the window -- the tail of the previous
   // window's buffer when there is one (its kernels may still be running), else what the last call saved
-  for (int r = 0; r < kPreGroup; ++r) {
+  for (int r = wave; r < kPreGroup; r += kPreWaves) {
     const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
     const float *hist = a.xh_prev ? a.xh_prev + (int64_t)sr * a.xh_prev_stride + (a.xh_prev_stride - kPitchBuf)
                                   : a.state + (int64_t)sr * SuppState::kCount + SuppState::kHist;
 #pragma unroll 9
     for (int i = lane; i < kPitchBuf; i += 64) a.xh[(int64_t)sr * xh_stride + i] = hist[i];
   }
+
+  // per-role state
+  float m0 = 0.0f, m1 = 0.0f, dc_x1 = 0.0f, dc_y1 = 0.0f;
+  double z1 = 0.0, z2 = 0.0;
+  if (wave == 3) {
+    m0 = st[SuppState::kHpMem];
+    m1 = st[SuppState::kHpMem + 1];
+  }
+  if (wave == 1 && kDcHp) {  // realtime front end state (chain planes): DC block x1/y1 (f32), 80 Hz high-pass z1/z2 (f64)
+    dc_x1 = a.chain_st32[(int64_t)a.f32_dc_x1 * NS + sc];
+    dc_y1 = a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + sc];
+    z1 = a.chain_st64[(int64_t)a.f64_pre_z1 * NS + sc];
+    z2 = a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + sc];
+  }
   const float b0 = -2.0f, b1 = 1.0f, a0 = -1.99599f, a1 = 0.99600f;  // RNNoise input high-pass
   const double hb0 = a.hp_b0, hb1 = a.hp_b1, hb2 = a.hp_b2, ha1 = a.hp_a1, ha2 = a.hp_a2;
   const bool hp_on = a.front_hp != 0;
-  for (int64_t ti = 0; ti < ntiles; ++ti) {
-    const int64_t t0 = ti * 64;
-    const int len = (int)((n - t0) < 64 ? (n - t0) : 64);
+
+  for (int64_t it = 0; it < ntiles + 4; ++it) {
+    if (wave == 0) {  // ---- load tile `it` (rows are clamped, not skipped: the 64 loads stay in flight together)
+      const int64_t ti = it;
+      if (ti < ntiles) {
+        const int len = tile_len(ti);
+        const int64_t col = a.frame0 * kRnnFrame + ti * 64 + (lane < len ? lane : len - 1);
+        float v[kPreGroup];
 #pragma unroll
-    for (int r = 0; r < kPreGroup; ++r) tile[lane][r] = nxt[r];
-    __syncthreads();
-    if (ti + 1 < ntiles) fetch(t0 + 64);
-    for (int c0 = 0; c0 < len; c0 += kPreChunk) {
-      float x[kPreChunk], d[kPreChunk];
+        for (int r = 0; r < kPreGroup; ++r) {
+          const int sr = (s0 + r) < a.n_streams ? (s0 + r) : a.n_streams - 1;
+          v[r] = a.in[(int64_t)sr * a.in_stride + col];
+        }
+        float *tile = t_in + (ti & 1) * kPreTile;
 #pragma unroll
-      for (int t = 0; t < kPreChunk; ++t) x[t] = tile[c0 + t][lane];
-#pragma unroll
-      for (int t = 0; t < kPreChunk; ++t) {
-        if (c0 + t < len) {
-          float v = x[t];
-          if (kFront) {
-            if (!finite32(v)) v = 0.0f;                                        // routing.rs:808-811
-            if (kClamp) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);        // routing.rs:822
-            if (kDcHp) {                                                       // routing.rs:832-840
-              const float o = v - dc_x1 + 0.995f * dc_y1;
-              dc_x1 = v;
-              dc_y1 = o;
-              v = o;
-              if (hp_on) {
-                const double xin = (double)o;
-                const double y = hb0 * xin + z1;
-                z1 = hb1 * xin - ha1 * y + z2;
-                z2 = hb2 * xin - ha2 * y;
-                v = (float)y;
+        for (int r = 0; r < kPreGroup; ++r) at(tile, lane, r) = v[r];
+      }
+    } else if (wave == 1) {  // ---- front end on tile it - 1 (lane = stream): routing.rs:802-843
+      const int64_t ti = it - 1;
+      if (ti >= 0 && ti < ntiles) {
+        const int len = tile_len(ti);
+        float *src = t_in + (ti & 1) * kPreTile, *dst = t_dry + (ti & 1) * kPreTile;
+#pragma unroll 8
+        for (int t = 0; t < 64; ++t) {
+          if (t < len) {
+            float v = at(src, t, lane);
+            if (kFront) {
+              if (!finite32(v)) v = 0.0f;                                        // routing.rs:808-811
+              if (kClamp) v = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);        // routing.rs:822
+              if (kDcHp) {                                                       // routing.rs:832-840
+                const float o = v - dc_x1 + 0.995f * dc_y1;
+                dc_x1 = v;
+                dc_y1 = o;
+                v = o;
+                if (hp_on) {
+                  const double xin = (double)o;
+                  const double y = hb0 * xin + z1;
+                  z1 = hb1 * xin - ha1 * y + z2;
+                  z2 = hb2 * xin - ha2 * y;
+                  v = (float)y;
+                }
               }
             }
-            d[t] = v;
+            at(dst, t, lane) = v;
           }
+        }
+      }
+    } else if (wave == 2) {  // ---- model-input scaling of tile it - 2 (lane = time)
+      const int64_t ti = it - 2;
+      if (ti >= 0 && ti < ntiles) {
+        float *src = t_dry + (ti & 1) * kPreTile, *dst = t_sc + (ti & 1) * kPreTile;
+#pragma unroll 8
+        for (int r = 0; r < kPreGroup; ++r) {
+          float v = at(src, lane, r);
           if (kRaw) {  // bin/rnnoise_benchmark.rs:75-79
             v = (v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v)) * 32768.0f;
           } else {
             v = scale_for_model(v);
           }
-          const float y = v + m0;
-          m0 = m1 + (b0 * v - a0 * y);
-          m1 = (b1 * v - a1 * y);
-          x[t] = y;
+          at(dst, lane, r) = v;
         }
       }
-#pragma unroll
-      for (int t = 0; t < kPreChunk; ++t) {
-        tile[c0 + t][lane] = x[t];  // own column: nobody else reads it before the barrier
-        if (kFront) dry[c0 + t][lane] = d[t];
-      }
-    }
-    __syncthreads();
+    } else if (wave == 3) {  // ---- the model's own high-pass on tile it - 3 (lane = stream)
+      const int64_t ti = it - 3;
+      if (ti >= 0 && ti < ntiles) {
+        const int len = tile_len(ti);
+        float *src = t_sc + (ti & 1) * kPreTile, *dst = t_xh + (ti & 1) * kPreTile;
 #pragma unroll 8
-    for (int r = 0; r < kPreGroup; ++r) {
-      const int sr = s0 + r;
-      if (sr < a.n_streams && lane < len) {
-        a.xh[(int64_t)sr * xh_stride + kPitchBuf + t0 + lane] = tile[lane][r];
-        // the dry signal the wet/dry mix sees is the suppressor's input, i.e. the front end's output
-        if (kFront) a.out[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + t0 + lane] = dry[lane][r];
+        for (int t = 0; t < 64; ++t) {
+          if (t < len) {
+            const float v = at(src, t, lane);
+            const float y = v + m0;
+            m0 = m1 + (b0 * v - a0 * y);
+            m1 = (b1 * v - a1 * y);
+            at(dst, t, lane) = y;
+          }
+        }
+      }
+    } else if (wave == 4) {  // ---- the dry signal the wet/dry mix sees is the suppressor's input, i.e. the front end's output
+      const int64_t ti = it - 2;
+      if (kFront && ti >= 0 && ti < ntiles) {
+        const int len = tile_len(ti);
+        float *src = t_dry + (ti & 1) * kPreTile;
+#pragma unroll 8
+        for (int r = 0; r < kPreGroup; ++r) {
+          const int sr = s0 + r;
+          if (sr < a.n_streams && lane < len)
+            a.out[(int64_t)sr * a.stream_stride + a.frame0 * kRnnFrame + ti * 64 + lane] = at(src, lane, r);
+        }
+      }
+    } else {  // ---- the model input of tile it - 4
+      const int64_t ti = it - 4;
+      if (ti >= 0 && ti < ntiles) {
+        const int len = tile_len(ti);
+        float *src = t_xh + (ti & 1) * kPreTile;
+#pragma unroll 8
+        for (int r = 0; r < kPreGroup; ++r) {
+          const int sr = s0 + r;
+          if (sr < a.n_streams && lane < len) a.xh[(int64_t)sr * xh_stride + kPitchBuf + ti * 64 + lane] = at(src, lane, r);
+        }
       }
     }
     __syncthreads();
   }
-  if (valid) {
+  if (valid && wave == 3) {
     st[SuppState::kHpMem] = m0;
     st[SuppState::kHpMem + 1] = m1;
-    if (kDcHp) {
-      a.chain_st32[(int64_t)a.f32_dc_x1 * NS + s] = dc_x1;
-      a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + s] = dc_y1;
-      a.chain_st64[(int64_t)a.f64_pre_z1 * NS + s] = z1;
-      a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + s] = z2;
-    }
+  }
+  if (valid && wave == 1 && kDcHp) {
+    a.chain_st32[(int64_t)a.f32_dc_x1 * NS + s] = dc_x1;
+    a.chain_st32[(int64_t)(a.f32_dc_x1 + 1) * NS + s] = dc_y1;
+    a.chain_st64[(int64_t)a.f64_pre_z1 * NS + s] = z1;
+    a.chain_st64[(int64_t)(a.f64_pre_z1 + 1) * NS + s] = z2;
   }
 }
 
@@ -1581,20 +1623,32 @@ extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a)
 
 // ============================================================================== launch
 // The sample-serial pre-pass of a window (independent of the other kernels: it may run a window ahead).
+template <bool kClamp, bool kDcHp, bool kRaw>
+static hipError_t launch_prefilter_variant(const SuppArgs &a, hipStream_t stream) {
+  constexpr size_t lds = sizeof(float) * 8 * kPreTile;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(supp_prefilter_kernel<kClamp, kDcHp, kRaw>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return err;
+    attr_set = true;
+  }
+  const dim3 grid((a.n_streams + kPreGroup - 1) / kPreGroup), block(64 * kPreWaves);
+  hipLaunchKernelGGL((supp_prefilter_kernel<kClamp, kDcHp, kRaw>), grid, block, lds, stream, a);
+  return hipGetLastError();
+}
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream) {
-  const dim3 grid((a.n_streams + kPreGroup - 1) / kPreGroup), block(64);
   const int sel = (a.front_clamp ? 4 : 0) | (a.front_dc ? 2 : 0) | (a.raw_protocol ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((supp_prefilter_kernel<false, false, false>), grid, block, 0, stream, a); break;
-    case 1: hipLaunchKernelGGL((supp_prefilter_kernel<false, false, true>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((supp_prefilter_kernel<false, true, false>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((supp_prefilter_kernel<false, true, true>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((supp_prefilter_kernel<true, false, false>), grid, block, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((supp_prefilter_kernel<true, false, true>), grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((supp_prefilter_kernel<true, true, false>), grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL((supp_prefilter_kernel<true, true, true>), grid, block, 0, stream, a); break;
+    case 0: return launch_prefilter_variant<false, false, false>(a, stream);
+    case 1: return launch_prefilter_variant<false, false, true>(a, stream);
+    case 2: return launch_prefilter_variant<false, true, false>(a, stream);
+    case 3: return launch_prefilter_variant<false, true, true>(a, stream);
+    case 4: return launch_prefilter_variant<true, false, false>(a, stream);
+    case 5: return launch_prefilter_variant<true, false, true>(a, stream);
+    case 6: return launch_prefilter_variant<true, true, false>(a, stream);
+    default: return launch_prefilter_variant<true, true, true>(a, stream);
   }
-  return hipGetLastError();
 }
 
 // Analysis of one window: spectra, then pitch + cepstral features (frames in order per stream).
