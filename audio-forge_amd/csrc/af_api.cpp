@@ -169,6 +169,9 @@ struct af_engine {
     double *d_mk = nullptr;
     int64_t mk_rows = 0;                   // rows (blocks x streams) per set
     int64_t call_stride = 0;               // stream stride of the call being scheduled
+    const af::ChainParams *d_chain = nullptr;  // the parameter block(s) the stages read (an array with several presets)
+    int32_t w_min = 1;                     // smallest lookahead + 1 over the presets
+    uint32_t strip = 0;                    // chain flags another kernel has taken over (the suppressor's pre-pass)
   } pipe;
   int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
@@ -331,8 +334,8 @@ int ensure_started(af_engine *e) {
         if ((hp.flags & af::kFlagDeesser) || ((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled))
           return fail(AF_ERR_UNSUPPORTED, "the de-esser and auto-makeup passes are built for single-preset engines only");
       }
-      if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED)
-        return fail(AF_ERR_UNSUPPORTED, "multi-preset engines run the token-ring kernel");
+      if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED && e->kernel != AF_KERNEL_STAGED)
+        return fail(AF_ERR_UNSUPPORTED, "multi-preset engines run the token-ring kernel or the stage pipeline");
       const size_t n_groups = (size_t)(e->n_streams + 63) / 64;
       if (e->group_preset.size() != n_groups) e->group_preset.assign(n_groups, 0);
       if (e->d_group_preset) AF_HIP(hipFree(e->d_group_preset));
@@ -637,12 +640,28 @@ int engine_event(af_engine *e, hipEvent_t *out_ev) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The stage-pipeline form of the chain (af_stages.hip).  Which configurations it serves:
-bool stage_pipe_serves(const af_engine *e, const af::ChainParams &run, int32_t layout) {
-  if (!e->extra_presets.empty() || layout != AF_LAYOUT_STREAM_MAJOR) return false;
+bool stage_pipe_serves_one(const af::ChainParams &run) {
   if (run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
   if ((run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled) return false;
   if ((run.flags & af::kFlagEq) && run.n_eq_sections > 16) return false;
   if ((run.flags & af::kFlagLimiter) && run.lim.lookahead_samples > af::kMaxLookahead) return false;
+  return true;
+}
+// `run`: preset 0 as the chain will see it (the front end's flags stripped when the suppressor's pre-pass owns them)
+bool stage_pipe_serves(af_engine *e, const af::ChainParams &run, int32_t layout) {
+  if (layout != AF_LAYOUT_STREAM_MAJOR || !stage_pipe_serves_one(run)) return false;
+  const uint32_t strip = e->host_params.flags & ~run.flags;
+  for (int k = 1; k <= (int)e->extra_presets.size(); ++k) {
+    // several presets: every group's stages run as roles of the same dispatches, so the presets must agree on which stages
+    // there are and which code paths they take (what differs freely: every coefficient, the EQ, the limiter's lookahead)
+    af::ChainParams other = preset_params(e, k);
+    other.flags &= ~strip;
+    const uint32_t shape = af::kFlagCompressor | af::kFlagLimiter;
+    if (!stage_pipe_serves_one(other) || (other.flags & shape) != (run.flags & shape) ||
+        other.comp.sidechain_highpass_enabled != run.comp.sidechain_highpass_enabled ||
+        other.comp.adaptive_release != run.comp.adaptive_release || other.control_block != run.control_block)
+      return false;
+  }
   return true;
 }
 
@@ -717,6 +736,37 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   return AF_OK;
 }
 
+// The parameter block(s) the stage kernels read: preset 0 alone, or all presets as an array beside the group -> preset table.
+int stage_chain_params(af_engine *e, hipStream_t stream) {
+  auto &sp = e->pipe;
+  const int n_presets = 1 + (int)e->extra_presets.size();
+  std::vector<af::ChainParams> runs((size_t)n_presets);
+  sp.w_min = 1 << 30;
+  for (int k = 0; k < n_presets; ++k) {
+    runs[k] = preset_params(e, k);
+    runs[k].flags &= ~sp.strip;
+    sp.w_min = std::min<int32_t>(sp.w_min, runs[k].lim.lookahead_samples + 1);
+  }
+  if (n_presets == 1) {
+    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &runs[0], sizeof runs[0]) != 0) {
+      e->uploaded = runs[0];
+      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof runs[0], hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+      e->uploaded_valid = true;
+    }
+    sp.d_chain = e->d_params;
+  } else {
+    if (e->uploaded_multi.size() != runs.size() ||
+        std::memcmp(e->uploaded_multi.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
+      e->uploaded_multi = runs;
+      AF_HIP(hipMemcpyAsync(e->d_params_multi, e->uploaded_multi.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
+      AF_HIP(hipStreamSynchronize(stream));
+    }
+    sp.d_chain = e->d_params_multi;
+  }
+  return AF_OK;
+}
+
 // ---- the pipeline as one launch per step (af_stages.h, DiagArgs): launch j runs stage k on window j - skew(k) -----------------
 // The stages of this configuration in chain order, each one launch step behind the stage it reads from.
 struct StagePlan {
@@ -749,12 +799,12 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
                     hipStream_t stream) {
   auto &sp = e->pipe;
   af::DiagArgs d{};
-  d.base.params = e->d_params;
-  d.base.group_preset = nullptr;
+  d.base.params = sp.d_chain;
+  d.base.group_preset = e->extra_presets.empty() ? nullptr : e->d_group_preset;
   d.base.st64 = e->d_st64;
   d.base.st32 = e->d_st32;
   d.base.n_streams = e->n_streams;
-  d.base.w_min = run.lim.lookahead_samples + 1;
+  d.base.w_min = sp.w_min;
   d.base.r = sp.rings;
   d.params_eq = e->d_params_eq;
   d.flags = run.flags;
@@ -797,19 +847,25 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
 }
 
 // the EQ stage's parameter block for the window about to enter the pipeline (stream-ordered behind the previous window's launch)
-int stage_diag_eq_params(af_engine *e, const af::ChainParams &run, hipStream_t stream, bool *crossfade) {
+int stage_diag_eq_params(af_engine *e, hipStream_t stream, bool *crossfade) {
+  const int n_presets = 1 + (int)e->extra_presets.size();
+  std::vector<af::ChainParams> runs((size_t)n_presets);
   *crossfade = false;
-  for (int k = 0; k < run.n_eq_sections; ++k) *crossfade |= run.eq[k].xf_remaining > 0;
-  if (!e->d_params_eq || e->eq_params_presets != 1) {
+  for (int p = 0; p < n_presets; ++p) {
+    runs[p] = preset_params(e, p);
+    runs[p].flags &= ~e->pipe.strip;
+    for (int k = 0; k < runs[p].n_eq_sections; ++k) *crossfade |= runs[p].eq[k].xf_remaining > 0;
+  }
+  if (!e->d_params_eq || e->eq_params_presets != n_presets) {
     if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
     e->d_params_eq = nullptr;
-    AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams)));
-    e->eq_params_presets = 1;
+    AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets));
+    e->eq_params_presets = n_presets;
     e->uploaded_eq.clear();
   }
-  if (e->uploaded_eq.size() != 1 || std::memcmp(e->uploaded_eq.data(), &run, sizeof run) != 0) {
-    e->uploaded_eq.assign(1, run);
-    AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof run, hipMemcpyHostToDevice, stream));
+  if (e->uploaded_eq.size() != runs.size() || std::memcmp(e->uploaded_eq.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
+    e->uploaded_eq = runs;
+    AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
     AF_HIP(hipStreamSynchronize(stream));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
   }
   return AF_OK;
@@ -1222,7 +1278,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }();
     if (e->kernel == AF_KERNEL_STAGED && !serves)
       return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, auto-makeup, front end without the "
-                                      "suppressor, more than 16 EQ sections, several presets, time-major audio)");
+                                      "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
@@ -1236,15 +1292,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     int64_t tw = (int64_t)cb * std::max<int64_t>(1, 2880 / cb);
     if (const char *env = std::getenv("AF_STAGE_WINDOW")) tw = (int64_t)cb * std::max<int64_t>(1, std::atoll(env) / cb);
     if (int rc = stage_pipe_prepare(e, std::max<int64_t>(tw, e->pipe.tw_max))) return rc;
-    {
-      const af::ChainParams &run = e->host_params;  // what the stage kernels read (everything but the EQ sections)
-      if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
-        e->uploaded = run;
-        AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
-        AF_HIP(hipStreamSynchronize(stream));
-        e->uploaded_valid = true;
-      }
-    }
+    e->pipe.strip = 0;
+    if (int rc = stage_chain_params(e, stream)) return rc;  // what the stage kernels read (everything but the EQ sections)
     e->last_kernel_used = AF_KERNEL_STAGED;
     {
       // one launch step per window on the caller's stream: step j runs every stage on the window it has reached
@@ -1269,11 +1318,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       for (int64_t j = 0; j < steps; ++j) {
         if (j < (int64_t)wins.size()) {  // window j enters: its EQ stage reads the section parameters as they stand now
           bool crossfade = false;
-          if (int rc = stage_diag_eq_params(e, e->host_params, stream, &crossfade)) return rc;
+          if (int rc = stage_diag_eq_params(e, stream, &crossfade)) return rc;
           wins[(size_t)j].eq_crossfade = crossfade ? 1 : 0;
           advance_crossfades(e, wins[(size_t)j].n);
         }
-        if (int rc = stage_diag_step(e, e->uploaded, plan, wins, j, stream)) return rc;
+        if (int rc = stage_diag_step(e, e->host_params, plan, wins, j, stream)) return rc;
       }
       e->pipe.windows += (int64_t)wins.size();
       if (e->timing) {
@@ -1375,12 +1424,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     int64_t longest = std::max<int64_t>(unit, (window_frames / unit) * unit);
     for (int64_t nf : win_nf) longest = std::max(longest, nf);
     if (int rc = stage_pipe_prepare(e, std::max<int64_t>(longest * af::kRnnFrame, e->pipe.tw_max))) return rc;
-    if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {  // (everything but the EQ sections is read from here)
-      e->uploaded = run;
-      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      e->uploaded_valid = true;
-    }
+    e->pipe.strip = e->host_params.flags & ~run.flags;  // what the pre-pass has taken over
+    if (int rc = stage_chain_params(e, stream)) return rc;  // (everything but the EQ sections is read from here)
   }
   if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
     e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = stream;
@@ -1562,7 +1607,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       AF_HIP(hipStreamWaitEvent(ds, syn_done[w], 0));
       AF_HIP(hipMemsetAsync(wd.stats, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
       bool crossfade = false;
-      if (int rc2 = stage_diag_eq_params(e, run, ds, &crossfade)) return rc2;
+      if (int rc2 = stage_diag_eq_params(e, ds, &crossfade)) return rc2;
       wd.eq_crossfade = crossfade ? 1 : 0;
       diag_wins.push_back(wd);
       e->last_kernel_used = AF_KERNEL_STAGED;

@@ -22,7 +22,7 @@
 // floating-point expressions), so the two kernels agree bit for bit; tests/test_gpu_stages.py holds them to that.
 //
 // Not built in this form (the host keeps such configurations on kernel 2): the de-esser, auto-makeup, the front end
-// without the suppressor, more than 16 EQ sections, several presets, the time-major boundary layout.
+// without the suppressor, more than 16 EQ sections, presets that differ in which stages run, the time-major layout.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   const float *lim_in = comp ? a.r.xc : a.r.xe;
   switch (role.stage) {
     case kStEq: {
-      EqSystolicArgs ea{d.params_eq + role.win.eq_slot, nullptr, a.st64, a.in, nullptr, a.r.xe, a.r.xi, nullptr,
+      EqSystolicArgs ea{d.params_eq + role.win.eq_slot, a.group_preset, a.st64, a.in, nullptr, a.r.xe, a.r.xi, nullptr,
                         a.n, a.stream_stride, a.n0, a.n_streams, a.r.rows_f32};
       if (role.win.eq_crossfade) eq_systolic_body<false, true>(ea, bx);
       else eq_systolic_body<false, false>(ea, bx);

@@ -200,3 +200,43 @@ def test_randomized_configurations_against_the_other_kernels(core):
             assert_same(got, want)
         except AssertionError as err:
             raise AssertionError(f"case {case}: fs {fs}, {n_streams} streams, calls {calls}, settings {settings}: {err}") from None
+
+
+def test_several_presets_in_one_engine(core):
+    """Three presets over 150 streams (one per 64-stream group) that agree on which stages run and differ in everything else
+    (EQ layout incl. section counts, thresholds, time constants, ceilings, lookahead): the stage pipeline reads each group's
+    own parameter block like kernel 2 does -- same bits, two calls."""
+    import ctypes as C
+
+    from mic_eq_mi import _lib
+
+    steep = list(S.DEFAULT_TYPED_BANDS)
+    steep[0] = ("high_pass", 90.0, 0.0, 0.707, 36, True)
+    steep[4] = ("bell", 1000.0, 6.0, 2.0, 12, True)
+    presets = [
+        (LEGACY_BANDS, dict(S.limiter_settings(2.0))),
+        (S.LIMITER_BANDS, dict(S.limiter_settings(1.0), compressor_threshold_db=-30.0, compressor_ratio=2.0, compressor_release_ms=90.0,
+                               limiter_ceiling_db=-3.0, limiter_careful_output_enabled=False)),
+        (S.LIMITER_BANDS, dict(S.limiter_settings(0.5), compressor_makeup_gain_db=6.0, compressor_attack_ms=2.0, eq_bands_v2=steep)),
+    ]
+    audio = S.batch_signal(150, 40) * np.float32(1.7)
+    outs = {}
+    for kernel in (_lib.KERNEL_PHASED, _lib.KERNEL_STAGED):
+        eng = core.Engine(48_000.0, 150)
+        try:
+            eng.set_preset_count(3)
+            for k, (bands, settings) in enumerate(presets):
+                eng.select_preset(k)
+                core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)
+            gp = np.asarray([2, 0, 1], dtype=np.int32)
+            _lib.check(eng._lib.af_engine_assign_presets(eng._h, gp.ctypes.data_as(C.POINTER(C.c_int32)), 3))
+            eng.set_kernel(kernel)
+            ys, rows = [], []
+            for lo, hi in ((0, 7001), (7001, audio.shape[1])):
+                ys.append(eng.process(audio[:, lo:hi]))
+                rows.append(eng.block_stats().copy())
+            assert eng._lib.af_engine_last_kernel(eng._h) == kernel
+            outs[kernel] = (np.concatenate(ys, axis=1), np.concatenate(rows, axis=0))
+        finally:
+            eng.close()
+    assert_same(outs[_lib.KERNEL_STAGED], outs[_lib.KERNEL_PHASED])
