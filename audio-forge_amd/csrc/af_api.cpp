@@ -168,6 +168,8 @@ struct af_engine {
     static constexpr int kMkSets = 4;
     double *d_mk = nullptr;
     int64_t mk_rows = 0;                   // rows (blocks x streams) per set
+    static constexpr int kBpSets = 16;
+    double *d_bp = nullptr;                // auto-makeup: block powers, written seven launch steps before they are read
     int64_t call_stride = 0;               // stream stride of the call being scheduled
     const af::ChainParams *d_chain = nullptr;  // the parameter block(s) the stages read (an array with several presets)
     int32_t w_min = 1;                     // smallest lookahead + 1 over the presets
@@ -642,7 +644,6 @@ int engine_event(af_engine *e, hipEvent_t *out_ev) {
 // The stage-pipeline form of the chain (af_stages.hip).  Which configurations it serves:
 bool stage_pipe_serves_one(const af::ChainParams &run) {
   if (run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
-  if ((run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled) return false;
   if ((run.flags & af::kFlagEq) && run.n_eq_sections > 16) return false;
   if ((run.flags & af::kFlagLimiter) && run.lim.lookahead_samples > af::kMaxLookahead) return false;
   return true;
@@ -659,7 +660,8 @@ bool stage_pipe_serves(af_engine *e, const af::ChainParams &run, int32_t layout)
     const uint32_t shape = af::kFlagCompressor | af::kFlagLimiter;
     if (!stage_pipe_serves_one(other) || (other.flags & shape) != (run.flags & shape) ||
         other.comp.sidechain_highpass_enabled != run.comp.sidechain_highpass_enabled ||
-        other.comp.adaptive_release != run.comp.adaptive_release || other.control_block != run.control_block)
+        other.comp.adaptive_release != run.comp.adaptive_release || other.comp.auto_makeup_enabled != run.comp.auto_makeup_enabled ||
+        other.control_block != run.control_block)
       return false;
   }
   return true;
@@ -704,13 +706,15 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   };
   af::StageRings &r = sp.rings;
   for (float **p : {&r.xi, &r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.gt, &r.od}) AF_HIP(ring32(p));
-  for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.fast_r, &r.slow_r, &r.tgt_ms, &r.tg, &r.g})
+  for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.glin, &r.fast_r, &r.slow_r, &r.tgt_ms, &r.tg, &r.g})
     AF_HIP(ring64(p));
   sp.tw_max = tw_max;
   const int cb = e->host_params.control_block;
   sp.mk_rows = ((tw_max + cb - 1) / cb + 1) * e->n_streams;
   if (sp.d_mk) (void)hipFree(sp.d_mk);
   AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
+  if (sp.d_bp) (void)hipFree(sp.d_bp);
+  AF_HIP(hipMalloc(&sp.d_bp, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kBpSets));
   if (!sp.stream) {  // (a queue of its own: a CU-masked stream with every CU enabled; plain streams share a few hardware queues)
     hipDeviceProp_t prop;
     AF_HIP(hipGetDeviceProperties(&prop, e->device));
@@ -730,7 +734,7 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   const int64_t groups = (e->n_streams + 63) / 64;
   af::StageRings &r = sp.rings;
   for (float *p : {r.xi, r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.gt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
-  for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.fast_r, r.slow_r, r.tgt_ms, r.tg, r.g})
+  for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.glin, r.fast_r, r.slow_r, r.tgt_ms, r.tg, r.g})
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
   sp.windows = 0;
   return AF_OK;
@@ -785,7 +789,13 @@ StagePlan stage_plan(const af::ChainParams &run) {
       add(af::kStFR, at + 1);
       add(af::kStRel, at + 2);
     }
-    at = add(af::kStF3, at + 1);
+    if (run.comp.auto_makeup_enabled) {
+      add(af::kStPow, 1);
+      at = add(af::kStF3a, at + 1);
+      at = add(af::kStMakeup, at + 1);
+    } else {
+      at = add(af::kStF3, at + 1);
+    }
   }
   if (lim)
     for (int k : {af::kStF4, af::kStLim, af::kStF5, af::kStTp}) at = add(k, at + 1);
@@ -810,6 +820,7 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
   d.flags = run.flags;
   d.sidechain = run.comp.sidechain_highpass_enabled;
   d.adaptive = run.comp.adaptive_release;
+  d.auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
   d.base.stream_stride = sp.call_stride;
   // two dispatches per step: the one-wave workgroups (serial stages and F4), then the wide stages
   for (int pass = 0; pass < 2; ++pass) {
@@ -817,7 +828,7 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
     d.n_roles = 0;
     for (int i = 0; i < plan.n; ++i) {
       const int k = plan.stage[i];
-      const bool wide = k == af::kStF1 || k == af::kStF2 || k == af::kStFR || k == af::kStF3 || k == af::kStF5 || k == af::kStF6;
+      const bool wide = k == af::kStF1 || k == af::kStF2 || k == af::kStFR || k == af::kStF3 || k == af::kStF3a || k == af::kStF5 || k == af::kStF6;
       if (wide != (pass == 1)) continue;
       const int64_t wi = j - plan.skew[i];
       if (wi < 0 || wi >= (int64_t)wins.size()) continue;
@@ -927,6 +938,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipDeviceSynchronize();
     for (void *p : e->pipe.allocs) (void)hipFree(p);
     (void)hipFree(e->pipe.d_mk);
+    (void)hipFree(e->pipe.d_bp);
   }
   if (e->pipe.stream) (void)hipStreamDestroy(e->pipe.stream);
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
@@ -1277,7 +1289,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       return env ? std::atoi(env) : -1;
     }();
     if (e->kernel == AF_KERNEL_STAGED && !serves)
-      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, auto-makeup, front end without the "
+      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, front end without the "
                                       "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
@@ -1307,6 +1319,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         wd.n = n_w;
         wd.stats = e->d_stats + blocks_at * e->n_streams;
         wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
+        wd.bp = e->pipe.d_bp + ((e->pipe.windows + (int64_t)wins.size()) % af_engine::StagePipe::kBpSets) * e->pipe.mk_rows;
+        wd.vad = e->has_evidence ? e->d_vad + blocks_at * e->n_streams : nullptr;
         wd.in = in + t0;
         wd.out = out + t0;
         wins.push_back(wd);
@@ -1602,6 +1616,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       wd.n = seg_n;
       wd.stats = e->d_stats + blocks_done * e->n_streams;
       wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
+      wd.bp = e->pipe.d_bp + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kBpSets) * e->pipe.mk_rows;
+      wd.vad = vad;
       wd.in = out + seg0;
       wd.out = out + seg0;
       AF_HIP(hipStreamWaitEvent(ds, syn_done[w], 0));

@@ -22,6 +22,7 @@ struct StageRings {
   double *peak_db;                               // log-domain peak envelope
   double *target;                                // static gain-reduction target (dB)
   double *gr;                                    // smoothed gain reduction (dB)
+  double *glin;                                  // auto-makeup only: its linear gain, 10^(-gr / 20)
   double *fast_r, *slow_r, *tgt_ms;              // adaptive release only: the envelopes each step found, the release time they ask for
   float *xc;                                     // limiter input (compressor output)
   float *sfx;                                    // suffix maxima of |xc| inside lookahead-aligned blocks
@@ -41,6 +42,8 @@ struct StageArgs {
   float *st32;
   BlockStats *stats;            // rows of this window: [block][stream]
   double *mk;                   // [blocks of this window][stream]: linear makeup gain in force during the block
+  double *bp;                   // auto-makeup: [blocks of this window][stream] square sum of the compressor's input
+  const double *vad;            // auto-makeup: [blocks of this window][stream] speech posteriors, or null
   const float *in;              // stream-major audio at the two ends of the pipeline (`in`: read by the EQ stage only)
   float *out;
   int64_t stream_stride;
@@ -61,6 +64,9 @@ enum StageId : int {
   kStF2,       // blended detector level -> gain-reduction target
   kStCompE,    // serial: release meter + gain-reduction smoothing, makeup gain per block
   kStF3,       // apply gain
+  kStPow,      // serial, auto-makeup: block power of the compressor's input (what the two-launch form's pre-pass measures)
+  kStF3a,      // auto-makeup: linear gain of the gain reduction
+  kStMakeup,   // serial, auto-makeup: makeup gain, K-weighted loudness meter, the controller (compressor.rs:528-653,700-774)
   kStFR,       // adaptive release: target release time from the envelopes
   kStRel,      // serial, adaptive release: release-time smoothing (feeds no other stage)
   kStF4,       // limiter: sliding maximum over the lookahead window -> target gain
@@ -79,7 +85,8 @@ enum StageId : int {
 struct DiagWin {               // what differs from window to window
   int64_t n0, n;
   BlockStats *stats;
-  double *mk;
+  double *mk, *bp;
+  const double *vad;
   const float *in;
   float *out;
   int32_t eq_slot;             // index into params_eq (0)
@@ -96,7 +103,7 @@ struct DiagArgs {
   DiagRole roles[kStCount];
   int32_t n_roles;
   uint32_t flags;              // chain flags the pipeline was planned for
-  int32_t sidechain, adaptive; // compressor switches (they pick code paths)
+  int32_t sidechain, adaptive, auto_makeup;  // compressor switches (they pick code paths)
 };
 // `wide`: the roles are the wide stages F1, F2, FR, F3, F5, F6 (workgroups of four waves); else all the others (one wave)
 hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream);

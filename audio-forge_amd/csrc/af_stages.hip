@@ -21,7 +21,7 @@
 // Arithmetic: the expressions are those of the token-ring kernel, operation for operation (the build does not contract
 // floating-point expressions), so the two kernels agree bit for bit; tests/test_gpu_stages.py holds them to that.
 //
-// Not built in this form (the host keeps such configurations on kernel 2): the de-esser, auto-makeup, the front end
+// Not built in this form (the host keeps such configurations on kernel 2): the de-esser, the front end
 // without the suppressor, more than 16 EQ sections, presets that differ in which stages run, the time-major layout.
 #include <hip/hip_runtime.h>
 
@@ -475,7 +475,7 @@ __device__ __forceinline__ void stage_f2_body(const StageArgs &a, int bx, int by
 
 // ============================================================================================ compressor, serial part E
 // release-time meter + gain-reduction smoothing, makeup gain per control block (compressor.rs:452-505,604-617,752-764)
-template <bool kAdaptive>
+template <bool kAdaptive, bool kAuto>
 __device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, int by) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
@@ -505,10 +505,14 @@ __device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, in
   BlockStats *stats = a.stats;
   int in_block = 0;
   int64_t b = 0;
-  if (w.valid) mk[w.s] = makeup_lin;  // the gain in force during the window's first block
+  if (w.valid && !kAuto) mk[w.s] = makeup_lin;  // the gain in force during the window's first block
   auto block_end = [&]() {  // wave-uniform: a control block (or the window) ends after the step just made
     const int blk_len = in_block;
     if (w.valid && stats) stats[b * w.NS + w.s].compressor_gr_db = (float)gr;
+    if (kAuto) {  // the makeup gain belongs to the makeup stage
+      b += 1;
+      return;
+    }
     // update_auto_makeup_gain with auto-makeup off (compressor.rs:604-617)
     const double makeup_coeff = pow(makeup_smoothing_coeff, (double)(blk_len < 1 ? 1 : blk_len));
     const double tgt = makeup_gain_db;
@@ -583,7 +587,7 @@ __device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, in
       a.st64[(int64_t)kCompCurReleaseMs * w.NS + w.s] = cur_ms;
       a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.s] = tgt_ms;
     }
-    a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
+    if (!kAuto) a.st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
   }
 }
 
@@ -635,6 +639,216 @@ __device__ __forceinline__ void stage_rel_body(const StageArgs &a, int bx, int b
     a.st64[(int64_t)kCompTargetReleaseMs * w.NS + w.s] = tgt_ms;
     const double tau = fmax(cur_ms, 0.001) / 1000.0;  // compressor.rs:760-761
     a.st64[(int64_t)kCompReleaseCoeff * w.NS + w.s] = exp(-1.0 / (tau * sample_rate));
+  }
+}
+
+// ============================================================================================ auto-makeup (compressor.rs:528-653)
+// The controller needs the RMS of each whole control block of the compressor's INPUT before the block's first sample
+// (compressor.rs:710).  The token-ring kernel runs a launch of its own for that; here it is one more serial stage, seven
+// launch steps ahead of the stage that uses it.
+__device__ __forceinline__ void stage_pow_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in;
+  in.init(a.r.xe, w.g, w.lane, a.r.rows_f32, q_first);
+  const int cb = P.control_block;
+  double *bp = a.bp;
+  double sq = 0.0;
+  int in_block = 0;
+  int64_t b = 0;
+  auto block_end = [&]() {
+    if (w.valid) bp[b * w.NS + w.s] = sq;
+    sq = 0.0;
+    b += 1;
+  };
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const float o = cur[u];
+      if (finite_f32(o)) sq += (double)o * (double)o;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [] {}, [](int) {}, block_end);
+    in.template refill<kBuf>(qb);
+  });
+}
+
+__device__ __forceinline__ void stage_f3a_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
+  const int R = a.r.rows_f64;
+  const int64_t gb = (int64_t)g * R * kLanes;
+  const int i = threadIdx.x;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    a.r.glin[gb + e.idx] = db2lin(-a.r.gr[gb + e.idx]);
+  }
+}
+
+// makeup gain of the block, K-weighted momentary loudness of what leaves the compressor (fed blocks only), the controller
+// at block end -- the token-ring kernel's makeup token, operation for operation
+__device__ __forceinline__ void stage_makeup_body(const StageArgs &a, int bx, int by) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  const CompressorParams cp = P.comp;  // by value (see the serial stages above)
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in_x;
+  Ahead<double> in_g;
+  in_x.init(a.r.xe, w.g, w.lane, a.r.rows_f32, q_first);
+  in_g.init(a.r.glin, w.g, w.lane, a.r.rows_f64, q_first);
+  Out<float> o;
+  o.init(a.r.xc, w.g, w.lane, a.r.rows_f32);
+  const int cb = P.control_block;
+  const int mbase = kF64Fixed + 4 * P.n_eq_sections;
+  const bool meter = cp.meter_slots > 0;
+  double *st64 = a.st64;
+  BlockStats *stats = a.stats;
+  const double *bp = a.bp, *vad = a.vad;
+  double sm = st64[(int64_t)kCompSmoothedMakeup * w.NS + w.sc];
+  double mk = db2lin(sm);
+  double v1 = meter ? st64[(int64_t)(mbase + kMeterV1) * w.NS + w.sc] : 0.0, v2 = meter ? st64[(int64_t)(mbase + kMeterV2) * w.NS + w.sc] : 0.0;
+  double v3 = meter ? st64[(int64_t)(mbase + kMeterV3) * w.NS + w.sc] : 0.0, v4 = meter ? st64[(int64_t)(mbase + kMeterV4) * w.NS + w.sc] : 0.0;
+  double score_state = st64[(int64_t)kCompActivityScore * w.NS + w.sc], relst_state = st64[(int64_t)kCompActivityReliability * w.NS + w.sc];
+  double lufs = st64[(int64_t)kCompCurrentLufs * w.NS + w.sc];
+  double acc = 0.0, act = 0.0, rel = 0.0;
+  bool fed = false;
+  int in_block = 0;
+  int64_t b = 0;
+  auto block_start = [&]() {
+    // estimate_auto_makeup_activity(block_rms_db(buffer), evidence), compressor.rs:528-596,710
+    const int64_t left = n - b * cb;
+    const int blk_len = (int)(left < cb ? left : cb);
+    const double power = bp[b * w.NS + w.sc] / (double)blk_len;
+    const double brms_db = lin2db(sqrt(power), 1e-10);
+    double absolute = 0.0;
+    if (brms_db >= -55.0 && brms_db <= -6.0)
+      absolute = fmin(dclamp(div_known(brms_db + 55.0, 12.0, 1.0 / 12.0), 0.0, 1.0), dclamp(div_known(-6.0 - brms_db, 6.0, 1.0 / 6.0), 0.0, 1.0));
+    act = absolute;
+    rel = 1.0;
+    if (cp.has_evidence) {
+      double vad_rel = cp.vad_reliability;
+      double vad_p = vad ? vad[b * w.NS + w.sc] : 0.0;
+      if (!(fabs(vad_p) < HUGE_VAL) || vad_p != vad_p) {
+        vad_rel = 0.0;
+        vad_p = 0.0;
+      }
+      vad_p = dclamp(vad_p, 0.0, 1.0);
+      const double configured = cp.noise_reference_reliability;
+      const double live = cp.live_noise_reliability;
+      double noise_rel = configured > 0.0 ? fmin(live, configured) : live;
+      double relative = 0.0;
+      const double nf = cp.noise_floor_db;
+      if (nf >= -120.0 && nf <= 0.0) {
+        const double e0 = nf + 3.0, e1 = nf + 15.0;
+        const double t = dclamp((brms_db - e0) / (e1 - e0), 0.0, 1.0);
+        relative = t * t * (3.0 - 2.0 * t);
+      } else {
+        noise_rel = 0.0;
+      }
+      const double fallback = noise_rel * relative + (1.0 - noise_rel) * absolute;
+      act = dclamp(vad_rel * vad_p + (1.0 - vad_rel) * fallback, 0.0, 1.0);
+      rel = dclamp(fmax(vad_rel, 0.75 * noise_rel), 0.0, 1.0);
+    }
+    fed = act > 0.20 && rel >= 0.35 && cp.meter_slots > 0;  // compressor.rs:714-720
+    acc = 0.0;
+  };
+  auto block_end = [&]() {
+    const int blk_len = in_block;
+    if (fed) {
+      const double tiny = 2.2250738585072014e-308;
+      if (fabs(v1) < tiny) v1 = 0.0;
+      if (fabs(v2) < tiny) v2 = 0.0;
+      if (fabs(v3) < tiny) v3 = 0.0;
+      if (fabs(v4) < tiny) v4 = 0.0;
+      // 400 ms window = the last meter_slots fed blocks (block energies instead of 19 200 samples)
+      const int written = (int)st64[(int64_t)(mbase + kMeterPos) * w.NS + w.sc];
+      const int pos = written + 1 == cp.meter_slots ? 0 : written + 1;
+      if (w.valid) {
+        st64[(int64_t)(mbase + kMeterRing + written) * w.NS + w.s] = acc;
+        st64[(int64_t)(mbase + kMeterPos) * w.NS + w.s] = (double)pos;
+      }
+      double sum = 0.0;
+      for (int m = 0; m < cp.meter_slots; ++m) {
+        const double e = m == written ? acc : st64[(int64_t)(mbase + kMeterRing + m) * w.NS + w.sc];
+        sum += e;
+      }
+      const double energy = sum / cp.meter_frames;
+      lufs = energy <= 0.0 ? -HUGE_VAL : (double)(float)(10.0 * (log(energy) / log(10.0)) - 0.691);
+    }
+    // update_auto_makeup_gain, compressor.rs:598-653
+    const bool whole = blk_len == cb;
+    const double elapsed = (double)(blk_len < 1 ? 1 : blk_len);
+    const double mc = whole ? cp.makeup_pow_cb : pow(cp.makeup_smoothing_coeff, elapsed);
+    const double rc2 = whole ? cp.relax_pow_cb : pow(cp.makeup_silence_relax_coeff, elapsed);
+    const double ac = whole ? cp.activity_pow_cb : pow(cp.speech_activity_smoothing_coeff, elapsed);
+    const double score = ac * score_state + (1.0 - ac) * dclamp(act, 0.0, 1.0);
+    const double relst = dclamp(rel, 0.0, 1.0);
+    score_state = score;
+    relst_state = relst;
+    if (score < 0.20) {
+      sm = rc2 * sm + (1.0 - rc2) * cp.makeup_gain_db;
+    } else if (relst < 0.35) {
+      const double cap = cp.makeup_gain_db + 3.0 * (relst / 0.35);
+      if (sm > cap) sm = mc * sm + (1.0 - mc) * cap;
+    } else {
+      const double required = cp.target_lufs - lufs;
+      const double reliability_cap = dclamp(12.0 * relst, 3.0, 12.0);
+      const double headroom_cap = dclamp(12.0, 0.0, reliability_cap);  // limiter feedback is 0 offline
+      const double clamped = dclamp(required, 0.0, headroom_cap);
+      if (fabs(clamped - sm) > 0.1) {
+        sm = mc * sm + (1.0 - mc) * clamped;
+      } else {
+        sm = clamped;
+      }
+    }
+    mk = db2lin(sm);
+    if (w.valid && stats) {
+      BlockStats &row = stats[b * w.NS + w.s];
+      row.makeup_gain_db = (float)sm;
+      row.makeup_activity = (float)score;
+      row.makeup_reliability = (float)relst;
+    }
+    b += 1;
+    if (b * cb < n) block_start();
+  };
+  if (n > 0) block_start();
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur_x)[kU] = in_x.template buf<kBuf>();
+    const double(&cur_g)[kU] = in_g.template buf<kBuf>();
+    auto step = [&](int u) {
+      const float x = (float)((double)cur_x[u] * (cur_g[u] * mk));
+      if (fed) {  // K-weighting, one 4th-order direct-form section (loudness.rs:119-127 over ebur128)
+        const double v0 = (double)x - cp.kw_a[1] * v1 - cp.kw_a[2] * v2 - cp.kw_a[3] * v3 - cp.kw_a[4] * v4;
+        const double y = cp.kw_b[0] * v0 + cp.kw_b[1] * v1 + cp.kw_b[2] * v2 + cp.kw_b[3] * v3 + cp.kw_b[4] * v4;
+        v4 = v3;
+        v3 = v2;
+        v2 = v1;
+        v1 = v0;
+        acc += y * y;
+      }
+      o.v[u] = x;
+    };
+    run_block<true>(qb, n0, n, cb, in_block, step, [&] { o.store_all(qb); }, [&](int u) { o.store_one(qb, u); }, block_end);
+    in_x.template refill<kBuf>(qb);
+    in_g.template refill<kBuf>(qb);
+  });
+  if (w.valid) {
+    st64[(int64_t)kCompSmoothedMakeup * w.NS + w.s] = sm;
+    st64[(int64_t)kCompActivityScore * w.NS + w.s] = score_state;
+    st64[(int64_t)kCompActivityReliability * w.NS + w.s] = relst_state;
+    st64[(int64_t)kCompCurrentLufs * w.NS + w.s] = lufs;
+    if (meter) {
+      st64[(int64_t)(mbase + kMeterV1) * w.NS + w.s] = v1;
+      st64[(int64_t)(mbase + kMeterV2) * w.NS + w.s] = v2;
+      st64[(int64_t)(mbase + kMeterV3) * w.NS + w.s] = v3;
+      st64[(int64_t)(mbase + kMeterV4) * w.NS + w.s] = v4;
+    }
   }
 }
 
@@ -1043,6 +1257,8 @@ __device__ __forceinline__ StageArgs role_args(const DiagArgs &d, const DiagRole
   a.n = role.win.n;
   a.stats = role.win.stats;
   a.mk = role.win.mk;
+  a.bp = role.win.bp;
+  a.vad = role.win.vad;
   a.in = role.win.in;
   a.out = role.win.out;
   return a;
@@ -1074,9 +1290,16 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
       break;
     case kStCompC: stage_comp_c_body(a, bx, by); break;
     case kStCompE:
-      if (d.adaptive) stage_comp_e_body<true>(a, bx, by);
-      else stage_comp_e_body<false>(a, bx, by);
+      if (d.auto_makeup) {
+        if (d.adaptive) stage_comp_e_body<true, true>(a, bx, by);
+        else stage_comp_e_body<false, true>(a, bx, by);
+      } else {
+        if (d.adaptive) stage_comp_e_body<true, false>(a, bx, by);
+        else stage_comp_e_body<false, false>(a, bx, by);
+      }
       break;
+    case kStPow: stage_pow_body(a, bx, by); break;
+    case kStMakeup: stage_makeup_body(a, bx, by); break;
     case kStRel: stage_rel_body(a, bx, by); break;
     case kStF4: stage_f4_body(a, lim_in, bx, by); break;
     case kStLim: stage_lim_body(a, bx, by); break;
@@ -1101,6 +1324,7 @@ __global__ __launch_bounds__(256) void stage_diag_wide_kernel(DiagArgs d) {
     case kStF2: stage_f2_body(a, bx, by); break;
     case kStFR: stage_fr_body(a, bx, by); break;
     case kStF3: stage_f3_body(a, bx, by); break;
+    case kStF3a: stage_f3a_body(a, bx, by); break;
     case kStF5: stage_f5_body(a, lim_in, bx, by); break;
     case kStF6: stage_f6_body(a, bx, by); break;
     default: break;
@@ -1117,7 +1341,7 @@ unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, 
   *gy = groups;
   switch (stage) {
     case kStEq: *gy = 1; return (unsigned)((n_streams + 3) / 4);  // four streams per wave
-    case kStF1: case kStF2: case kStF3: case kStFR: return (quads + kFfQuads - 1) / kFfQuads;
+    case kStF1: case kStF2: case kStF3: case kStF3a: case kStFR: return (quads + kFfQuads - 1) / kFfQuads;
     case kStF4: return (unsigned)(n / (w_min > 0 ? w_min : 1) + 2);
     case kStF5: case kStF6: return tiles;
     default: *gy = 1; return groups;  // serial stages: one workgroup (its first wave) per group

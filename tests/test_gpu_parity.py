@@ -319,8 +319,8 @@ def test_auto_makeup_control_traces(mi, oracle):
     """simulate_auto_makeup_control (python_api.rs:118-276): per-block controller traces + audio.
     The loudness meter (ebur128, not vendored) is spec-restated on both sides; its 400 ms window is
     summed per control block on the GPU, hence the 1e-6 dB tolerance on the traces."""
-    if not os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring"):
-        pytest.skip("auto-makeup lives in the token-ring kernel")
+    if not (os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring") or os.environ.get("AF_KERNEL_VARIANT", "") == "staged"):
+        pytest.skip("auto-makeup lives in the token-ring kernel and the stage pipeline")
     x = S.kat_signal(400)
     vad = (np.abs(np.sin(np.arange(400) * 0.05)) > 0.3).astype(float)
     for probs, settings in ((vad, {"return_output_audio": True}), ([], {"return_output_audio": True, "adaptive_release": False})):
@@ -337,8 +337,8 @@ def test_auto_makeup_control_traces(mi, oracle):
 def test_auto_makeup_inside_full_chain(mi, oracle):
     """compressor_auto_makeup_enabled=True through simulate_auto_eq_chain (EQ ahead of the compressor:
     two launches on the GPU)."""
-    if not os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring"):
-        pytest.skip("auto-makeup lives in the token-ring kernel")
+    if not (os.environ.get("AF_KERNEL_VARIANT", "").startswith("ring") or os.environ.get("AF_KERNEL_VARIANT", "") == "staged"):
+        pytest.skip("auto-makeup lives in the token-ring kernel and the stage pipeline")
     settings = dict(S.limiter_settings(2.0), compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0)
     bands = list(S.LIMITER_BANDS)
     bands[3] = (bands[3][0], 4.0, 1.2)

@@ -63,6 +63,8 @@ CASES = {
     "limiter only": {"compressor_enabled": False},
     "neither": {"compressor_enabled": False, "limiter_enabled": False},
     "short lookahead": {"limiter_lookahead_ms": 0.5},
+    "auto makeup": {"compressor_auto_makeup_enabled": True, "compressor_target_lufs": -16.0},
+    "auto makeup, adaptive": {"compressor_auto_makeup_enabled": True, "compressor_adaptive_release": True, "limiter_enabled": False},
     "long lookahead": {"limiter_lookahead_ms": 5.0},
 }
 
