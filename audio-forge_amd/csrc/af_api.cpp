@@ -676,6 +676,19 @@ size_t pow2_at_least(int64_t n) {
 // rings sized for windows of up to `tw_max` samples
 int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   auto &sp = e->pipe;
+  {  // the per-block arrays (makeup gains, block powers): a reset may have brought a shorter control block, i.e. more blocks
+    const int cb = e->host_params.control_block;
+    const int64_t rows = ((std::max(tw_max, sp.tw_max) + cb - 1) / cb + 1) * e->n_streams;
+    if (rows > sp.mk_rows) {
+      if (sp.d_mk || sp.d_bp) AF_HIP(hipDeviceSynchronize());
+      if (sp.d_mk) (void)hipFree(sp.d_mk);
+      if (sp.d_bp) (void)hipFree(sp.d_bp);
+      sp.d_mk = sp.d_bp = nullptr;
+      AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * rows * af_engine::StagePipe::kMkSets));
+      AF_HIP(hipMalloc(&sp.d_bp, sizeof(double) * rows * af_engine::StagePipe::kBpSets));
+      sp.mk_rows = rows;
+    }
+  }
   if (sp.rings.xe && tw_max <= sp.tw_max) return AF_OK;
   if (sp.rings.xe) {  // grow: only between calls of a fresh engine (the rings hold the histories)
     if (sp.windows > 0) return fail(AF_ERR_UNSUPPORTED, "a call of %lld samples per window after smaller ones: the stage pipeline's rings were sized for %lld",
@@ -709,12 +722,6 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.glin, &r.fast_r, &r.slow_r, &r.tgt_ms, &r.tg, &r.g})
     AF_HIP(ring64(p));
   sp.tw_max = tw_max;
-  const int cb = e->host_params.control_block;
-  sp.mk_rows = ((tw_max + cb - 1) / cb + 1) * e->n_streams;
-  if (sp.d_mk) (void)hipFree(sp.d_mk);
-  AF_HIP(hipMalloc(&sp.d_mk, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kMkSets));
-  if (sp.d_bp) (void)hipFree(sp.d_bp);
-  AF_HIP(hipMalloc(&sp.d_bp, sizeof(double) * sp.mk_rows * af_engine::StagePipe::kBpSets));
   if (!sp.stream) {  // (a queue of its own: a CU-masked stream with every CU enabled; plain streams share a few hardware queues)
     hipDeviceProp_t prop;
     AF_HIP(hipGetDeviceProperties(&prop, e->device));

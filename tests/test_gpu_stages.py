@@ -242,3 +242,36 @@ def test_several_presets_in_one_engine(core):
         finally:
             eng.close()
     assert_same(outs[_lib.KERNEL_STAGED], outs[_lib.KERNEL_PHASED])
+
+
+def test_engine_reuse_after_reset_with_shorter_control_blocks(core):
+    """An engine that ran the pipeline, is reset, reconfigured with shorter control blocks (more rows per window in the
+    per-block arrays) and run again gives what a fresh engine gives."""
+    from mic_eq_mi import _lib
+
+    audio = S.batch_signal(70, 30) * np.float32(1.5)
+    settings = dict(S.limiter_settings(2.0), compressor_auto_makeup_enabled=True)
+    settings["eq_bands_v2"] = TYPED_BANDS
+
+    def second_config(eng):
+        core.configure_auto_eq_chain(eng, 48_000.0, S.LIMITER_BANDS, dict(settings, compressor_threshold_db=-28.0))
+        eng.set_control_block_samples(480)
+        eng.set_kernel(_lib.KERNEL_STAGED)
+
+    eng = core.Engine(48_000.0, 70)
+    try:
+        core.configure_auto_eq_chain(eng, 48_000.0, S.LIMITER_BANDS, settings)
+        eng.set_kernel(_lib.KERNEL_STAGED)
+        eng.process(audio)
+        eng.reset()
+        second_config(eng)
+        got = (eng.process(audio), eng.block_stats().copy())
+    finally:
+        eng.close()
+    fresh = core.Engine(48_000.0, 70)
+    try:
+        second_config(fresh)
+        want = (fresh.process(audio), fresh.block_stats().copy())
+    finally:
+        fresh.close()
+    assert_same(got, want)
