@@ -394,15 +394,28 @@ __device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by
   const int s = g * kLanes + lane;
   const int64_t NS = a.n_streams;
   const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  double i_low[kFfQuads], i_voiced[kFfQuads], i_pres[kFfQuads], i_rms[kFfQuads], i_d[kFfQuads];  // (loaded ahead: see stage F5)
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    const int64_t row = gb + qoff(q0 + k, R) + i;
+    if (cp.sidechain_highpass_enabled) {
+      i_low[k] = a.r.low_e[row];
+      i_voiced[k] = a.r.voiced_e[row];
+      i_pres[k] = a.r.pres_e[row];
+    }
+    i_rms[k] = a.r.rms_e[row];
+    i_d[k] = a.r.d[row];
+  }
+#pragma unroll
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const int64_t row = gb + e.idx;
     double weight_db = 0.0, plosive_last = 0.0;
     if (cp.sidechain_highpass_enabled) {
-      const double low_rms = sqrt(a.r.low_e[row]);
-      const double voiced_rms = fmax(sqrt(a.r.voiced_e[row]), 1e-8);
-      const double presence_rms = sqrt(a.r.pres_e[row]);
+      const double low_rms = sqrt(i_low[k]);
+      const double voiced_rms = fmax(sqrt(i_voiced[k]), 1e-8);
+      const double presence_rms = sqrt(i_pres[k]);
       const double plosive = dclamp(low_rms / voiced_rms, 0.0, 32.0);
       plosive_last = plosive;
       const double plosive_amount = dclamp(div_known(plosive - 1.25, 3.75, 1.0 / 3.75), 0.0, 1.0);
@@ -412,8 +425,8 @@ __device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by
       weight_db = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
     }
     a.r.w_db[row] = weight_db;
-    a.r.ipk_db[row] = lin2db(fabs(a.r.d[row]), 1e-10);
-    a.r.rms_db[row] = lin2db(sqrt(a.r.rms_e[row]), 1e-10);
+    a.r.ipk_db[row] = lin2db(fabs(i_d[k]), 1e-10);
+    a.r.rms_db[row] = lin2db(sqrt(i_rms[k]), 1e-10);
     if (e.abs == a.n0 + a.n - 1 && s < a.n_streams) a.st64[(int64_t)kCompPlosive * NS + s] = plosive_last;  // diagnostic state only
   }
 }
@@ -464,12 +477,21 @@ __device__ __forceinline__ void stage_f2_body(const StageArgs &a, int bx, int by
   const int64_t gb = (int64_t)g * R * kLanes;
   const int i = threadIdx.x;
   const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  double pk[kFfQuads], rm[kFfQuads], wd[kFfQuads];  // (loaded ahead of the arithmetic: see stage F5)
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    const int64_t row = gb + qoff(q0 + k, R) + i;
+    pk[k] = a.r.peak_db[row];
+    rm[k] = a.r.rms_db[row];
+    wd[k] = a.r.w_db[row];
+  }
+#pragma unroll
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const int64_t row = gb + e.idx;
-    const double blended = 0.6 * db2lin(a.r.peak_db[row]) + 0.4 * db2lin(a.r.rms_db[row]);
-    a.r.target[row] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + a.r.w_db[row]);
+    const double blended = 0.6 * db2lin(pk[k]) + 0.4 * db2lin(rm[k]);
+    a.r.target[row] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + wd[k]);
   }
 }
 
@@ -865,13 +887,20 @@ __device__ __forceinline__ void stage_f3_body(const StageArgs &a, int bx, int by
   const int64_t NS = a.n_streams;
   const int cb = P.control_block;
   const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  double i_gr[kFfQuads];  // (loaded ahead of the arithmetic: see stage F5)
+  float i_x[kFfQuads];
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    i_gr[k] = a.r.gr[gb + qoff(q0 + k, R) + i];
+    i_x[k] = a.r.xe[gb32 + qoff(q0 + k, R32) + i];
+  }
+#pragma unroll
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const double makeup_lin = a.mk[((e.abs - a.n0) / cb) * NS + sc];
-    const double gr = a.r.gr[gb + e.idx];
     const int64_t row = gb32 + qoff(q0 + k, R32) + i;
-    a.r.xc[row] = (float)((double)a.r.xe[row] * (db2lin(-gr) * makeup_lin));
+    a.r.xc[row] = (float)((double)i_x[k] * (db2lin(-i_gr[k]) * makeup_lin));
   }
 }
 
@@ -1020,14 +1049,25 @@ __device__ __forceinline__ void stage_f5_body(const StageArgs &a, const float *x
   const int64_t n0 = a.n0, n_end = a.n0 + a.n;
   const int64_t abs0 = ((n0 >> 6) + bx) * kTileRows;  // first sample of the tile
   // samples abs0 - 32 .. abs0 + 63 of the limiter output (before the stream's first sample the rings hold zeros)
-  for (int i = wave; i < kTileRows + kTpTaps; i += 4) {
-    const int64_t n = abs0 - kTpTaps + i;
-    const float delayed = xin_ring[gb32 + eoff(n - la, w.lane, R32)];
-    const double gain = a.r.g[gb + eoff(n, w.lane, R)];
-    const float o = (float)dclamp((double)delayed * gain, -ceil_lin, ceil_lin);
-    const float v = finite_f32(o) ? o : 0.0f;  // TruePeakLimiter input scrub, true_peak.rs:342
-    xl_t[i][w.lane] = v;
-    if (n >= n0 && n < n_end && i >= kTpTaps) a.r.xl[gb32 + eoff(n, w.lane, R32)] = v;
+  {  // (all of a wave's 24 row pairs are loaded before the first is used: the launch is short, a load's latency is not)
+    constexpr int kMine = (kTileRows + kTpTaps) / 4;
+    float delayed[kMine];
+    double gain[kMine];
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+      const int64_t n = abs0 - kTpTaps + wave + 4 * k;
+      delayed[k] = xin_ring[gb32 + eoff(n - la, w.lane, R32)];
+      gain[k] = a.r.g[gb + eoff(n, w.lane, R)];
+    }
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+      const int i = wave + 4 * k;
+      const int64_t n = abs0 - kTpTaps + i;
+      const float o = (float)dclamp((double)delayed[k] * gain[k], -ceil_lin, ceil_lin);
+      const float v = finite_f32(o) ? o : 0.0f;  // TruePeakLimiter input scrub, true_peak.rs:342
+      xl_t[i][w.lane] = v;
+      if (n >= n0 && n < n_end && i >= kTpTaps) a.r.xl[gb32 + eoff(n, w.lane, R32)] = v;
+    }
   }
   __syncthreads();
   float h[kTpTaps + 16];  // h[i]: sample abs0 + 16 * wave - 32 + i
