@@ -47,10 +47,10 @@ constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
 // AUTO routes the configurations the stage pipeline serves to it up to this many streams.  Measured (dynamics chain, 10 s,
-// one MI355X): 256 streams 50 ms against the token ring's 202, 1024 streams 84 against 202, 4096 streams 175 against 202;
-// beyond that the token ring wins (a launch of it lasts ~202 ms up to 16 384 streams) and the pipeline's rings (0.3 KB per
-// sample step per stream in flight) would take tens of GB.
-constexpr int kStagedAutoMaxStreams = 2048;
+// one MI355X): 256 streams 41 ms against the token ring's 202, 1024 streams 64, 2048 streams 91, 3072 streams 136, 4096
+// streams 202 (the hand-over rings cost 0.3 KB per sample step per stream: the HBM roof); beyond that the token ring wins
+// (a launch of it lasts ~202 ms up to 16 384 streams).  Behind the suppressor, whose kernels use the same HBM, up to 2048.
+constexpr int kStagedAutoMaxStreams = 3072, kStagedAutoMaxStreamsBehindSuppressor = 2048;
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
 static_assert(sizeof(af_block_stats) == 72, "stats row size");
@@ -1298,7 +1298,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (e->kernel == AF_KERNEL_STAGED && !serves)
       return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, front end without the "
                                       "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
-    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 && e->n_streams <= kStagedAutoMaxStreams) ||
+    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 &&
+                                 e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams)) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
     if (e->pipe.active)
