@@ -236,7 +236,7 @@ int af_engine_set_preset_count(af_engine *e, int32_t n);
 int32_t af_engine_preset_count(const af_engine *e);  /* VALUE */
 int af_engine_select_preset(af_engine *e, int32_t preset);
 int af_engine_assign_presets(af_engine *e, const int32_t *preset_of_group, int32_t n_groups);
-/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: up to 2048 streams AF_KERNEL_STAGED
+/* choose the kernel variant (AF_KERNEL_*); default AF_KERNEL_AUTO: up to 3072 streams (2048 behind the suppressor) AF_KERNEL_STAGED
  * (the chain as a pipeline of stage kernels, one per recurrence; not built for the de-esser, the front end without the
  * suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio: those fall through); else AF_KERNEL_PHASED
  * (the token ring, 64 streams per workgroup) wherever its LDS layout fits, AF_KERNEL_QUAD (16 streams per workgroup) for
