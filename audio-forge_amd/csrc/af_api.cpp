@@ -1467,7 +1467,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipGetDeviceProperties(&prop, e->device));
     const int total_cus = prop.multiProcessorCount;
     if (!(env && std::atoi(env) == 0) && total_cus % 32 == 0 && total_cus <= 1024) {
-      chain_cus = env && std::atoi(env) > 0 ? std::atoi(env) : ((chain_groups + 7) / 8) * 8;
+      // (a power of two: the workgroups of a launch are dealt to the XCDs in turn and 48 or 56 enabled CUs leave some of them
+      // with two workgroups each -- 3072 streams: 356 ms of chain launches per step on 48 CUs, 197 on 64)
+      int pow2 = 8;
+      while (pow2 < chain_groups) pow2 *= 2;
+      chain_cus = env && std::atoi(env) > 0 ? std::atoi(env) : pow2;
       if (chain_cus * 2 > total_cus) chain_cus = 0;  // a chain that wants half the chip or more shares all of it
     }
     if (chain_cus > 0) {
