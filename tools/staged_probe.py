@@ -23,6 +23,8 @@ for streams in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 el
         eng = core.Engine(48_000.0, streams)
         settings = dict(S.limiter_settings(2.0))
         settings["eq_bands_v2"] = TYPED
+        if os.environ.get("PROBE_DEESSER"):
+            settings["deesser_enabled"] = True
         if os.environ.get("PROBE_ADAPTIVE"):
             settings["compressor_adaptive_release"] = True
         core.configure_auto_eq_chain(eng, 48_000.0, S.LIMITER_BANDS, settings)
