@@ -212,7 +212,7 @@ __device__ __forceinline__ Elem ff_elem(const StageArgs &a, int64_t q, int i, in
 // ============================================================================================ block input statistics
 // input_square_sum (f64, in sample order) and input_sample_peak of every control block (block_processor.rs:111-118) from
 // the scrubbed input the EQ kernel leaves in the `xi` ring: two instructions on the recurrence, off the EQ's own loop
-__device__ __forceinline__ void stage_in_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_in_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const int64_t n = a.n, n0 = a.n0;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void stage_in_body(const StageArgs &a, int bx, int by
 // about a dozen instructions per step each: (1) the high-pass, the low band's envelope and the presence signal, (2) the
 // voiced, presence and rms envelopes
 template <bool kSc>
-__device__ __forceinline__ void stage_comp_a_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_comp_a_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void stage_comp_a_body(const StageArgs &a, int bx, in
 }
 
 template <bool kSc>
-__device__ __forceinline__ void stage_comp_a2_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_comp_a2_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
@@ -433,7 +433,7 @@ __device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by
 
 // ============================================================================================ compressor, serial part C
 // log-domain peak envelope (compressor.rs:735-742)
-__device__ __forceinline__ void stage_comp_c_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_comp_c_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
@@ -498,7 +498,7 @@ __device__ __forceinline__ void stage_f2_body(const StageArgs &a, int bx, int by
 // ============================================================================================ compressor, serial part E
 // release-time meter + gain-reduction smoothing, makeup gain per control block (compressor.rs:452-505,604-617,752-764)
 template <bool kAdaptive, bool kAuto>
-__device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_comp_e_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
@@ -633,7 +633,7 @@ __device__ __forceinline__ void stage_fr_body(const StageArgs &a, int bx, int by
   }
 }
 
-__device__ __forceinline__ void stage_rel_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_rel_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams &cp = P.comp;
@@ -668,7 +668,7 @@ __device__ __forceinline__ void stage_rel_body(const StageArgs &a, int bx, int b
 // The controller needs the RMS of each whole control block of the compressor's INPUT before the block's first sample
 // (compressor.rs:710).  The token-ring kernel runs a launch of its own for that; here it is one more serial stage, seven
 // launch steps ahead of the stage that uses it.
-__device__ __forceinline__ void stage_pow_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_pow_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const int64_t n = a.n, n0 = a.n0;
@@ -712,7 +712,7 @@ __device__ __forceinline__ void stage_f3a_body(const StageArgs &a, int bx, int b
 
 // makeup gain of the block, K-weighted momentary loudness of what leaves the compressor (fed blocks only), the controller
 // at block end -- the token-ring kernel's makeup token, operation for operation
-__device__ __forceinline__ void stage_makeup_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_makeup_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const CompressorParams cp = P.comp;  // by value (see the serial stages above)
@@ -978,7 +978,7 @@ __device__ __forceinline__ void stage_f4_body(const StageArgs &a, const float *x
 
 // ============================================================================================ limiter, serial part
 // gain smoothing (limiter.rs:271-284)
-__device__ __forceinline__ void stage_lim_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_lim_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void stage_f5_body(const StageArgs &a, const float *x
 // ============================================================================================ true-peak limiter, serial parts
 // (1) the gain (true_peak.rs:353-374) and the limiter's own block figures; (2) the chain output and the block output
 // statistics (block_processor.rs:150-170), whose square sum is a recurrence of its own
-__device__ __forceinline__ void stage_tp_body(const StageArgs &a, int bx, int by) {
+__device__ __forceinline__ void stage_tp_body(const StageArgs &a, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void stage_tp_body(const StageArgs &a, int bx, int by
 }
 
 template <bool kLim>
-__device__ __forceinline__ void stage_out_body(const StageArgs &a, const float *xin_ring, int bx, int by) {
+__device__ __forceinline__ void stage_out_body(const StageArgs &a, const float *xin_ring, int bx, int /*by*/) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   __builtin_amdgcn_s_setprio(3);
