@@ -6,7 +6,7 @@ RNNoise algorithm on seeded synthetic weights.  Tolerance: the two sides run dif
 factorizations in f32 (mixed radix on the CPU, 15x8x8 on the GPU), so spectra agree to ~1e-6
 relative; a pitch decision can flip on a near-tie, which shows up as one frame of larger error.
 We therefore require per-sample RMS error <= 1e-5 (north_star budget) on +-1 full scale and bound
-the worst sample at 2e-3.
+the worst sample at 1e-5 (measured: 2.4e-7).
 """
 import numpy as np
 import pytest
@@ -24,14 +24,18 @@ def mi():
     return mic_eq_mi
 
 
+WORST_SAMPLE = 1e-5  # measured: 1.2e-7 .. 2.4e-7 (round 1 allowed 2e-3 "in case a pitch decision flips": none does, and the full-size test counts them)
+
+
 def _check(got, want):
     assert got.shape == want.shape
     assert np.all(np.isfinite(got))
     d = got.astype(np.float64) - want.astype(np.float64)
     rms = float(np.sqrt(np.mean(d * d)))
     worst = float(np.max(np.abs(d)))
+    print(f"suppressor GPU vs restatement: rms {rms:.3e}, worst sample {worst:.3e}")
     assert rms <= 1e-5, (rms, worst)
-    assert worst <= 2e-3, (rms, worst)
+    assert worst <= WORST_SAMPLE, (rms, worst)
     return rms, worst
 
 
