@@ -1442,10 +1442,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->trace_frames = frames;
   }
   if (e->pipe.active) {
-    // (sized for the longest window any call can be cut into, not for this call's)
-    int64_t longest = std::max<int64_t>(unit, (window_frames / unit) * unit);
-    for (int64_t nf : win_nf) longest = std::max(longest, nf);
-    if (int rc = stage_pipe_prepare(e, std::max<int64_t>(longest * af::kRnnFrame, e->pipe.tw_max))) return rc;
+    // (a suppressor window enters the pipeline in pieces of the pipeline's own window length: the rings stay as small as
+    // without the suppressor)
+    const int64_t chain_tw = (int64_t)cb * std::max<int64_t>(1, 2880 / cb);
+    if (int rc = stage_pipe_prepare(e, std::max<int64_t>(chain_tw, e->pipe.tw_max))) return rc;
     e->pipe.strip = e->host_params.flags & ~run.flags;  // what the pre-pass has taken over
     if (int rc = stage_chain_params(e, stream)) return rc;  // (everything but the EQ sections is read from here)
   }
@@ -1623,25 +1623,31 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       // ---- the window's chain as one more step of the stage pipeline (af_stages.hip; small and medium batches): this window
       // enters (its EQ stage reads the overlap-add output), the windows before it move one stage on
       const hipStream_t ds = e->pipe.stream;
-      af::DiagWin wd{};
-      wd.n0 = e->samples_processed + seg0;
-      wd.n = seg_n;
-      wd.stats = e->d_stats + blocks_done * e->n_streams;
-      wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
-      wd.bp = e->pipe.d_bp + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kBpSets) * e->pipe.mk_rows;
-      wd.vad = vad;
-      wd.in = out + seg0;
-      wd.out = out + seg0;
+      const int64_t chain_tw = (int64_t)cb * std::max<int64_t>(1, 2880 / cb);
       AF_HIP(hipStreamWaitEvent(ds, syn_done[w], 0));
-      AF_HIP(hipMemsetAsync(wd.stats, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
-      bool crossfade = false;
-      if (int rc2 = stage_diag_eq_params(e, ds, &crossfade)) return rc2;
-      wd.eq_crossfade = crossfade ? 1 : 0;
-      diag_wins.push_back(wd);
+      AF_HIP(hipMemsetAsync(e->d_stats + blocks_done * e->n_streams, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
       e->last_kernel_used = AF_KERNEL_STAGED;
       e->pipe.call_stride = stream_stride;
-      if (int rc2 = stage_diag_step(e, run, diag_plan, diag_wins, (int64_t)diag_wins.size() - 1, ds)) return rc2;
-      advance_crossfades(e, seg_n);
+      int64_t sub_blocks = 0;
+      for (int64_t off = 0; off < seg_n; off += chain_tw) {
+        const int64_t n_sub = std::min<int64_t>(chain_tw, seg_n - off);
+        af::DiagWin wd{};
+        wd.n0 = e->samples_processed + seg0 + off;
+        wd.n = n_sub;
+        wd.stats = e->d_stats + (blocks_done + sub_blocks) * e->n_streams;
+        wd.mk = e->pipe.d_mk + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kMkSets) * e->pipe.mk_rows;
+        wd.bp = e->pipe.d_bp + ((e->pipe.windows + (int64_t)diag_wins.size()) % af_engine::StagePipe::kBpSets) * e->pipe.mk_rows;
+        wd.vad = vad ? vad + sub_blocks * e->n_streams : nullptr;
+        wd.in = out + seg0 + off;
+        wd.out = out + seg0 + off;
+        bool crossfade = false;
+        if (int rc2 = stage_diag_eq_params(e, ds, &crossfade)) return rc2;
+        wd.eq_crossfade = crossfade ? 1 : 0;
+        diag_wins.push_back(wd);
+        if (int rc2 = stage_diag_step(e, run, diag_plan, diag_wins, (int64_t)diag_wins.size() - 1, ds)) return rc2;
+        advance_crossfades(e, n_sub);
+        sub_blocks += (n_sub + cb - 1) / cb;
+      }
       run = e->host_params;  // crossfade bookkeeping may have moved on
       if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
       blocks_done += (seg_n + cb - 1) / cb;
