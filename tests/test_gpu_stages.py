@@ -159,9 +159,11 @@ def test_randomized_configurations_against_the_other_kernels(core):
     lookahead does not fit kernel 2's LDS layout), bit for bit.  What a hand-picked list of cases would miss."""
     from mic_eq_mi import _lib
 
-    rng = np.random.default_rng(20261004)
+    import os
+
+    rng = np.random.default_rng(int(os.environ.get("AF_RANDOM_SEED", "20261004")))
     kinds = ("bell", "low_shelf", "high_shelf", "high_pass", "low_pass", "notch")
-    for case in range(14):
+    for case in range(int(os.environ.get("AF_RANDOM_CASES", "14"))):  # (a soak run: AF_RANDOM_CASES=200 AF_RANDOM_SEED=...)
         fs = float(rng.choice([44_100.0, 48_000.0, 48_000.0, 96_000.0]))
         n_streams = int(rng.choice([1, 3, 64, 65, 130]))
         blocks = int(rng.integers(8, 60))
@@ -193,10 +195,17 @@ def test_randomized_configurations_against_the_other_kernels(core):
         calls = list(zip(edges[:-1], edges[1:]))
         lookahead_samples = round(lookahead * fs / 1000.0)
         ref_kernel = _lib.KERNEL_PHASED if lookahead_samples <= 120 else _lib.KERNEL_QUAD
+        if ref_kernel == _lib.KERNEL_PHASED and settings["compressor_enabled"] and rng.random() > 0.6:
+            settings["compressor_auto_makeup_enabled"] = True  # (only kernel 2 has it to compare with)
+            settings["compressor_target_lufs"] = float(rng.uniform(-24.0, -12.0))
         use_legacy = bool(rng.random() > 0.6)
         legacy = [(b[1], b[2], b[3]) for b in bands]
         kw = dict(bands=legacy if use_legacy else bands, fs=fs)
-        want = run(core, ref_kernel, audio, settings, calls, **kw)
+        try:
+            want = run(core, ref_kernel, audio, settings, calls, **kw)
+        except NotImplementedError:  # kernel 2's LDS layout does not hold this EQ / lookahead: kernel 3 is the yardstick
+            settings["compressor_auto_makeup_enabled"] = False
+            want = run(core, _lib.KERNEL_QUAD, audio, settings, calls, **kw)
         got = run(core, _lib.KERNEL_STAGED, audio, settings, calls, **kw)
         try:
             assert_same(got, want)
