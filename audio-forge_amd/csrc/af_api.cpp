@@ -42,7 +42,8 @@ hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32
                           int32_t layout, bool front_end, bool write_out_power, hipStream_t stream);
 hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
-                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream);
+                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream,
+                              double *block_power = nullptr);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
@@ -123,6 +124,24 @@ struct af_engine {
   af::BlockStats *d_stats_pre = nullptr;   // rows of the pre-pass launch (auto-makeup)
   int64_t stats_pre_capacity = 0;
   af::ChainParams *d_params_pre = nullptr;
+  af::ChainParams uploaded_pre{};          // what d_params_pre currently holds
+  bool uploaded_pre_valid = false;
+  double *d_block_power = nullptr;         // [blocks][streams] of the current call: compressor-input block power written by the systolic EQ
+  int64_t block_power_capacity = 0;        // doubles
+  // Parameter uploads go through engine-owned pinned staging slots (stage_upload): the host never waits for a stream, and
+  // a slot is only reused once the copy that read it has run.
+  struct ParamStager {
+    static constexpr int kSlots = 8;
+    af::ChainParams *pinned = nullptr;     // [kSlots][blocks_per_slot]
+    size_t blocks_per_slot = 0;
+    hipEvent_t done[kSlots] = {};
+    bool used[kSlots] = {};
+    int next = 0;
+  } stager;
+  // Device buffers that had to grow while earlier work may still read them: kept until that work has ended (an event on the
+  // stream the call was made on), freed by a later call, a reset or the destructor -- growing never synchronises the device.
+  struct Retired { void *p; hipEvent_t ev; };
+  std::vector<Retired> retired;
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
   hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
   hipStream_t eq_stream = nullptr;         // the window's systolic EQ (af_eq_systolic.hip), behind its overlap-add, beside the next window's synthesis
@@ -188,6 +207,64 @@ int require_config(af_engine *e) {
   if (e->started)
     return fail(AF_ERR_STATE, "setter called after streaming started; call af_engine_reset first");
   e->params_dirty = true;
+  return AF_OK;
+}
+
+// Copy `count` parameter blocks to the device behind everything already queued on `stream`, from a pinned engine-owned slot.
+int stage_upload(af_engine *e, af::ChainParams *dst, const af::ChainParams *src, size_t count, hipStream_t stream) {
+  auto &st = e->stager;
+  if (count > st.blocks_per_slot) {
+    for (int k = 0; k < af_engine::ParamStager::kSlots; ++k)
+      if (st.used[k]) { AF_HIP(hipEventSynchronize(st.done[k])); st.used[k] = false; }
+    if (st.pinned) AF_HIP(hipHostFree(st.pinned));
+    st.pinned = nullptr;
+    AF_HIP(hipHostMalloc(reinterpret_cast<void **>(&st.pinned), sizeof(af::ChainParams) * count * af_engine::ParamStager::kSlots, hipHostMallocDefault));
+    st.blocks_per_slot = count;
+  }
+  const int slot = st.next;
+  st.next = (st.next + 1) % af_engine::ParamStager::kSlots;
+  if (!st.done[slot]) AF_HIP(hipEventCreateWithFlags(&st.done[slot], hipEventDisableTiming));
+  if (st.used[slot]) AF_HIP(hipEventSynchronize(st.done[slot]));  // eight uploads ago: long done
+  af::ChainParams *host = st.pinned + (size_t)slot * st.blocks_per_slot;
+  std::memcpy(host, src, sizeof(af::ChainParams) * count);
+  AF_HIP(hipMemcpyAsync(dst, host, sizeof(af::ChainParams) * count, hipMemcpyHostToDevice, stream));
+  AF_HIP(hipEventRecord(st.done[slot], stream));
+  st.used[slot] = true;
+  return AF_OK;
+}
+
+// free the retired buffers whose last reader has ended (`all`: wait for them)
+int collect_retired(af_engine *e, bool all) {
+  size_t kept = 0;
+  for (auto &r : e->retired) {
+    hipError_t q = all ? hipEventSynchronize(r.ev) : hipEventQuery(r.ev);
+    if (q == hipSuccess) {
+      (void)hipFree(r.p);
+      (void)hipEventDestroy(r.ev);
+    } else {
+      if (q != hipErrorNotReady) (void)hipGetLastError();
+      e->retired[kept++] = r;
+    }
+  }
+  e->retired.resize(kept);
+  return AF_OK;
+}
+
+// Make `*p` hold at least `need` bytes.  Growth is geometric; the old buffer (its contents are per-call scratch, never
+// carried over) is retired behind an event on `stream` instead of being freed under the feet of queued kernels.
+int grow_device(af_engine *e, void **p, int64_t *capacity_bytes, int64_t need, hipStream_t stream) {
+  if (need <= *capacity_bytes) return AF_OK;
+  const int64_t cap = std::max<int64_t>(need, *capacity_bytes + *capacity_bytes / 2);
+  void *fresh = nullptr;
+  AF_HIP(hipMalloc(&fresh, (size_t)cap));
+  if (*p) {
+    hipEvent_t ev;
+    AF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    AF_HIP(hipEventRecord(ev, stream));
+    e->retired.push_back({*p, ev});
+  }
+  *p = fresh;
+  *capacity_bytes = cap;
   return AF_OK;
 }
 
@@ -429,9 +506,8 @@ int launch_chain_multi(af_engine *e, uint32_t strip, uint32_t add, const float *
   const int64_t rows = ((n_samples + cb - 1) / cb) * e->n_streams;
   if (e->uploaded_multi.size() != runs.size() ||
       std::memcmp(e->uploaded_multi.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
-    e->uploaded_multi = runs;  // engine-owned copy: stays valid until the async copy has run
-    AF_HIP(hipMemcpyAsync(e->d_params_multi, e->uploaded_multi.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
-    AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+    e->uploaded_multi = runs;  // (what the device holds; the copy itself reads a pinned slot)
+    if (int rc = stage_upload(e, e->d_params_multi, runs.data(), runs.size(), stream)) return rc;
   }
   af::LaunchArgs a{};
   a.st64 = e->d_st64;
@@ -470,8 +546,10 @@ int launch_chain_multi(af_engine *e, uint32_t strip, uint32_t add, const float *
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
                          af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/,
-                         bool stats_cleared = false) {
+                         bool stats_cleared = false, const double *pre_power = nullptr) {
   // `stats_cleared`: the rows were zeroed (and partly filled) by an earlier kernel of this window: do not clear them again
+  // `pre_power`: [block][stream] compressor-input block powers of this segment, left by the systolic EQ kernel that ran as
+  // the window's pre-pass: an auto-makeup segment is then ONE launch
   if (!e->extra_presets.empty())
     return launch_chain_multi(e, e->host_params.flags & ~run_in.flags, run_in.flags & af::kFlagInputDone, in, out, n_samples,
                               stream_stride, layout, samples_before, stats, stream, stats_cleared);
@@ -507,7 +585,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   const bool deesser = (run.flags & af::kFlagDeesser) != 0;
   const bool eq_first = (run.flags & af::kFlagEqBeforeDeesser) != 0;
   const uint32_t front_flags = af::kFlagInputScrub | af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass;
-  const bool two_pass = auto_makeup || (deesser && eq_first);
+  const bool two_pass = (auto_makeup && !pre_power) || (deesser && eq_first);
   if (two_pass && kernel != AF_KERNEL_PHASED)
     return fail(AF_ERR_UNSUPPORTED, "EQ-before-de-esser order is only built around the token-ring kernel");
   af::LaunchArgs a{};
@@ -529,21 +607,18 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     AF_HIP(hipEventCreate(&t1));
     AF_HIP(hipEventRecord(t0, stream));
   }
-  if ((two_pass || deesser) && rows > e->stats_pre_capacity) {
-    AF_HIP(hipStreamSynchronize(stream));
-    if (e->d_stats_pre) AF_HIP(hipFree(e->d_stats_pre));
-    if (e->d_stats_de) AF_HIP(hipFree(e->d_stats_de));
-    AF_HIP(hipMalloc(&e->d_stats_pre, sizeof(af::BlockStats) * rows));
-    AF_HIP(hipMalloc(&e->d_stats_de, sizeof(af::BlockStats) * rows));
-    e->stats_pre_capacity = rows;
+  if ((two_pass || deesser) && rows > e->stats_pre_capacity) {  // (per-call scratch: the old rows are retired, not freed)
+    int64_t cap_pre = e->stats_pre_capacity * (int64_t)sizeof(af::BlockStats), cap_de = cap_pre;
+    if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_stats_pre), &cap_pre, rows * (int64_t)sizeof(af::BlockStats), stream)) return rc;
+    if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_stats_de), &cap_de, rows * (int64_t)sizeof(af::BlockStats), stream)) return rc;
+    e->stats_pre_capacity = std::min(cap_pre, cap_de) / (int64_t)sizeof(af::BlockStats);
   }
   const af::BlockStats *input_rows = nullptr;  // where the block input statistics end up when a side pass saw the input
   if (deesser) {
     // the de-esser pass reads the unmodified parameter block (its own copy: the chain kernels get edited flags)
     if (!e->uploaded_de_valid || std::memcmp(&e->uploaded_de, &run_in, sizeof run_in) != 0) {
       e->uploaded_de = run_in;
-      AF_HIP(hipMemcpyAsync(e->d_params_de, &e->uploaded_de, sizeof run_in, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
+      if (int rc = stage_upload(e, e->d_params_de, &e->uploaded_de, 1, stream)) return rc;
       e->uploaded_de_valid = true;
     }
     AF_HIP(hipMemsetAsync(e->d_stats_de, 0, sizeof(af::BlockStats) * rows, stream));
@@ -565,10 +640,18 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       af::ChainParams pre = run, post = run;
       pre.flags = (pre.flags & ~(af::kFlagCompressor | af::kFlagLimiter)) | af::kFlagPrePass;
       post.flags &= ~(af::kFlagEq | front_flags);
-      AF_HIP(hipMemcpyAsync(e->d_params_pre, &pre, sizeof pre, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipMemcpyAsync(e->d_params, &post, sizeof post, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
-      e->uploaded_valid = false;  // d_params now holds the post-pass variant
+      // both variants are uploaded only when they change (first launch; while a coefficient crossfade advances), through
+      // pinned slots: no host wait inside a window loop
+      if (!e->uploaded_pre_valid || std::memcmp(&e->uploaded_pre, &pre, sizeof pre) != 0) {
+        e->uploaded_pre = pre;
+        if (int rc = stage_upload(e, e->d_params_pre, &e->uploaded_pre, 1, stream)) return rc;
+        e->uploaded_pre_valid = true;
+      }
+      if (!e->uploaded_valid || std::memcmp(&e->uploaded, &post, sizeof post) != 0) {
+        e->uploaded = post;
+        if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
+        e->uploaded_valid = true;
+      }
       AF_HIP(hipMemsetAsync(e->d_stats_pre, 0, sizeof(af::BlockStats) * rows, stream));
       af::LaunchArgs a1 = a;
       a1.params = e->d_params_pre;
@@ -593,19 +676,21 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
       e->last_launches += 2;
     } else {
       if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
-        e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
-        AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
-        AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+        e->uploaded = run;
+        if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
         e->uploaded_valid = true;
       }
-      AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+      if (auto_makeup) {  // the systolic EQ kernel was this segment's pre-pass
+        a.pre_power = pre_power;
+        a.vad_prob = vad;
+      }
+      AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, auto_makeup, stream));
       e->last_launches += 1;
     }
   } else {
     if (!e->uploaded_valid || std::memcmp(&e->uploaded, &run, sizeof run) != 0) {
-      e->uploaded = run;  // engine-owned copy: stays valid until the async copy has run
-      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof run, hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));  // rare: first launch, and while EQ crossfades advance
+      e->uploaded = run;
+      if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
       e->uploaded_valid = true;
     }
     if (kernel == AF_KERNEL_QUAD) {
@@ -761,8 +846,7 @@ int stage_chain_params(af_engine *e, hipStream_t stream) {
   if (n_presets == 1) {
     if (!e->uploaded_valid || std::memcmp(&e->uploaded, &runs[0], sizeof runs[0]) != 0) {
       e->uploaded = runs[0];
-      AF_HIP(hipMemcpyAsync(e->d_params, &e->uploaded, sizeof runs[0], hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
+      if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
       e->uploaded_valid = true;
     }
     sp.d_chain = e->d_params;
@@ -770,8 +854,7 @@ int stage_chain_params(af_engine *e, hipStream_t stream) {
     if (e->uploaded_multi.size() != runs.size() ||
         std::memcmp(e->uploaded_multi.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
       e->uploaded_multi = runs;
-      AF_HIP(hipMemcpyAsync(e->d_params_multi, e->uploaded_multi.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
-      AF_HIP(hipStreamSynchronize(stream));
+      if (int rc = stage_upload(e, e->d_params_multi, runs.data(), runs.size(), stream)) return rc;
     }
     sp.d_chain = e->d_params_multi;
   }
@@ -883,8 +966,7 @@ int stage_diag_eq_params(af_engine *e, hipStream_t stream, bool *crossfade) {
   }
   if (e->uploaded_eq.size() != runs.size() || std::memcmp(e->uploaded_eq.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
     e->uploaded_eq = runs;
-    AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof(af::ChainParams) * runs.size(), hipMemcpyHostToDevice, stream));
-    AF_HIP(hipStreamSynchronize(stream));  // rare (the host copy must outlive the transfer): first window, and while a crossfade runs
+    if (int rc = stage_upload(e, e->d_params_eq, runs.data(), runs.size(), stream)) return rc;
   }
   return AF_OK;
 }
@@ -936,6 +1018,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_params_multi);
     (void)hipFree(e->d_asm);
     (void)hipFree(e->d_trace);
+    (void)hipFree(e->d_block_power);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
@@ -946,6 +1029,13 @@ void af_engine_destroy(af_engine *e) {
     for (void *p : e->pipe.allocs) (void)hipFree(p);
     (void)hipFree(e->pipe.d_mk);
     (void)hipFree(e->pipe.d_bp);
+  }
+  if (!e->retired.empty() || e->stager.pinned) {
+    (void)hipSetDevice(e->device);
+    (void)collect_retired(e, true);
+    for (hipEvent_t ev : e->stager.done)
+      if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+    if (e->stager.pinned) (void)hipHostFree(e->stager.pinned);
   }
   if (e->pipe.stream) (void)hipStreamDestroy(e->pipe.stream);
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
@@ -969,8 +1059,10 @@ int af_engine_reset(af_engine *e) {
   if (e->started) {
     AF_HIP(hipSetDevice(e->device));
     AF_HIP(hipDeviceSynchronize());
+    (void)collect_retired(e, true);
   }
   e->started = false;
+  e->uploaded_valid = e->uploaded_pre_valid = e->uploaded_de_valid = false;
   e->pipe.decided = false;
   e->params_dirty = true;
   e->samples_processed = 0;
@@ -1208,33 +1300,60 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
                                               (long long)stream_stride, (long long)min_stride);
   if (int rc = ensure_started(e)) return rc;
   hipStream_t stream = (hipStream_t)hip_stream;
-  e->last_stream = stream;
-  // ---- RNNoise frame buffering (rnnoise.rs:114-164: push_samples -> process_frames -> pop).  The suppressor eats whole
-  // 480-sample frames; what a call leaves over waits in the engine for the next call, and a call returns the whole frames
-  // that are complete by then: floor((pending + n) / 480) * 480 samples per stream, which may be 0 or exceed n.
+  // ---- Everything that can refuse the call is checked before the engine's frame ring, its buffers or a stream are touched: a
+  // refused call leaves af_engine_pending_input and the audio state as they were.
+  // RNNoise frame buffering (rnnoise.rs:114-164: push_samples -> process_frames -> pop): the suppressor eats whole 480-sample
+  // frames; what a call leaves over waits in the engine for the next call, and a call returns the whole frames that are
+  // complete by then: floor((pending + n) / 480) * 480 samples per stream, which may be 0 or exceed n.
   const float *src = in;
   int64_t src_stride = stream_stride;
   const int64_t n_in = n_samples;
+  int64_t n_run = n_samples, rem = 0;
   if (e->supp.enabled) {
     if (layout != AF_LAYOUT_STREAM_MAJOR) return fail(AF_ERR_UNSUPPORTED, "the suppressor needs stream-major audio");
-    const int64_t B = e->n_streams;
     const int64_t total = e->pending + n_in;
-    const int64_t n_run = (total / af::kRnnFrame) * af::kRnnFrame;
-    const int64_t rem = total - n_run;
+    n_run = (total / af::kRnnFrame) * af::kRnnFrame;
+    rem = total - n_run;
     if (n_run > stream_stride)
       return fail(AF_ERR_INVALID_ARGUMENT, "this call completes %lld samples per stream (%d were pending): stream_stride %lld is too small",
                   (long long)n_run, e->pending, (long long)stream_stride);
+  }
+  const int cb = e->host_params.control_block;
+  const int64_t blocks = (n_run + cb - 1) / cb;
+  if (n_run > 0 && (e->host_params.flags & af::kFlagCompressor) && e->host_params.comp.auto_makeup_enabled && e->has_evidence &&
+      e->vad_blocks != blocks)
+    return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
+                (long long)blocks, (long long)e->vad_blocks);
+  if (n_run > 0 && !e->pipe.decided) {  // first call after a reset: which form of the chain this engine runs
+    af::ChainParams probe = e->host_params;
+    if (e->supp.enabled) probe.flags &= ~(af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub);
+    const bool serves = stage_pipe_serves(e, probe, layout);
+    static const int env_staged = [] {  // AF_STAGED=0 / 1: keep AUTO off / on the stage pipeline (A/B runs)
+      const char *env = std::getenv("AF_STAGED");
+      return env ? std::atoi(env) : -1;
+    }();
+    if (e->kernel == AF_KERNEL_STAGED && !serves)
+      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, front end without the "
+                                      "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
+    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 &&
+                                 e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams)) ||
+                                (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
+    e->pipe.decided = true;
+    if (e->pipe.active)
+      if (int rc = stage_pipe_clear(e)) return rc;
+  }
+  // ---- accepted: from here on the call only fails on a backend error
+  e->last_stream = stream;
+  (void)collect_retired(e, false);
+  if (e->supp.enabled) {
+    const int64_t B = e->n_streams;
     if (e->pending > 0 || rem > 0) {
       if (!e->d_pending) AF_HIP(hipMalloc(&e->d_pending, sizeof(float) * af::kRnnFrame * B));
       const size_t f4 = sizeof(float);
       if (n_run > 0) {
-        if (B * n_run > e->asm_capacity) {
-          AF_HIP(hipDeviceSynchronize());
-          if (e->d_asm) AF_HIP(hipFree(e->d_asm));
-          e->d_asm = nullptr;
-          AF_HIP(hipMalloc(&e->d_asm, f4 * B * n_run));
-          e->asm_capacity = B * n_run;
-        }
+        int64_t cap = e->asm_capacity * (int64_t)f4;  // (scratch of one call: grown geometrically, the old buffer retired)
+        if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_asm), &cap, B * n_run * (int64_t)f4, stream)) return rc;
+        e->asm_capacity = cap / (int64_t)f4;
         // [pending | head of this call] -> whole frames; the tail of this call waits (copied before anything writes `out`,
         // which may alias `in`)
         if (e->pending > 0)
@@ -1257,25 +1376,16 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   e->last_output_samples = n_samples;
   e->trace_frames = 0;
   e->ev_cursor = 0;
-  const int cb = e->host_params.control_block;
-  const int64_t blocks = (n_samples + cb - 1) / cb;
   e->last_blocks = blocks;
   e->last_kernel_ms = 0.0;
   e->last_launches = 0;
   if (n_samples == 0) return AF_OK;
   const int64_t rows = blocks * e->n_streams;
-  if (rows > e->stats_capacity) {
-    if (e->d_stats) {
-      AF_HIP(hipStreamSynchronize(stream));
-      AF_HIP(hipFree(e->d_stats));
-    }
-    AF_HIP(hipMalloc(&e->d_stats, sizeof(af::BlockStats) * rows));
-    e->stats_capacity = rows;
+  {
+    int64_t cap = e->stats_capacity * (int64_t)sizeof(af::BlockStats);
+    if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_stats), &cap, rows * (int64_t)sizeof(af::BlockStats), stream)) return rc;
+    e->stats_capacity = cap / (int64_t)sizeof(af::BlockStats);
   }
-  if ((e->host_params.flags & af::kFlagCompressor) && e->host_params.comp.auto_makeup_enabled && e->has_evidence &&
-      e->vad_blocks != blocks)
-    return fail(AF_ERR_INVALID_ARGUMENT, "expected %lld VAD probabilities at the control cadence, got %lld",
-                (long long)blocks, (long long)e->vad_blocks);
   if (e->timing) {
     if (!e->ev_start) {
       AF_HIP(hipEventCreate(&e->ev_start));
@@ -1287,24 +1397,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   e->chain_ms_events.clear();
 
-  if (!e->pipe.decided) {  // first call after a reset: which form of the chain this engine runs
-    af::ChainParams probe = e->host_params;
-    if (e->supp.enabled) probe.flags &= ~(af::kFlagInputClamp | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagInputScrub);
-    const bool serves = stage_pipe_serves(e, probe, layout);
-    static const int env_staged = [] {  // AF_STAGED=0 / 1: keep AUTO off / on the stage pipeline (A/B runs)
-      const char *env = std::getenv("AF_STAGED");
-      return env ? std::atoi(env) : -1;
-    }();
-    if (e->kernel == AF_KERNEL_STAGED && !serves)
-      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, front end without the "
-                                      "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
-    e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 &&
-                                 e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams)) ||
-                                (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
-    e->pipe.decided = true;
-    if (e->pipe.active)
-      if (int rc = stage_pipe_clear(e)) return rc;
-  }
   if (!e->supp.enabled && e->pipe.active) {
     // ---- the chain as a pipeline of stage kernels over windows of whole control blocks (af_stages.hip)
     // (a launch step costs ~20 us, the pipeline's fill is depth x window time: 960 samples 45.7 ms per 10 s at 256 streams,
@@ -1515,6 +1607,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   const bool eq_offload = eq_offload_env && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) &&
                           (e->ring_variant == 0 || e->ring_variant == 1604) && (run.flags & af::kFlagEq);
   bool eq_needs_chain_done = true;  // (the previous call's last chain launch has ended: the caller's stream waited for it)
+  const bool auto_makeup_call = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
+  if (eq_offload && auto_makeup_call && !e->pipe.active) {
+    // the systolic EQ kernel is then also the pre-pass of every window (it leaves the compressor-input block powers here)
+    int64_t cap = e->block_power_capacity * (int64_t)sizeof(double);
+    if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_block_power), &cap, rows * (int64_t)sizeof(double), stream)) return rc;
+    e->block_power_capacity = cap / (int64_t)sizeof(double);
+  }
   auto next_event = [&](hipEvent_t *out_ev) -> int { return engine_event(e, out_ev); };
   {  // the side streams start after whatever the caller queued before this call
     hipEvent_t ev;
@@ -1619,6 +1718,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     // one-launch form of the token-ring kernel and no coefficient crossfade is running
     af::ChainParams run_w = run;
     bool eq_offloaded = false;
+    double *power_w = nullptr;  // the window's block powers, when its systolic EQ launch was an auto-makeup pre-pass
     if (e->pipe.active && !diag_skip_chain) {
       // ---- the window's chain as one more step of the stage pipeline (af_stages.hip; small and medium batches): this window
       // enters (its EQ stage reads the overlap-add output), the windows before it move one stage on
@@ -1661,8 +1761,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         runs_eq[k] = preset_params(e, k);
         runs_eq[k].flags &= ~(e->host_params.flags & ~run.flags);  // what the pre-pass has taken over
         const af::ChainParams &hp = runs_eq[k];
-        ok = !(hp.flags & af::kFlagDeesser) && !((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled) &&
-             hp.n_eq_sections <= 16 && !(hp.flags & (af::kFlagDcBlock | af::kFlagPreHighpass)) &&
+        ok = !(hp.flags & af::kFlagDeesser) && hp.n_eq_sections <= 16 && !(hp.flags & (af::kFlagDcBlock | af::kFlagPreHighpass)) &&
              af::ring_kernel_dynamic_lds(hp.n_eq_sections, hp.lim.lookahead_samples, false) <= af::kMaxLdsBytes;
         for (int j = 0; j < hp.n_eq_sections; ++j) ok = ok && hp.eq[j].xf_remaining == 0;
       }
@@ -1679,8 +1778,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         if (e->uploaded_eq.size() != runs_eq.size() ||
             std::memcmp(e->uploaded_eq.data(), runs_eq.data(), sizeof(af::ChainParams) * runs_eq.size()) != 0) {
           e->uploaded_eq = runs_eq;
-          AF_HIP(hipMemcpyAsync(e->d_params_eq, e->uploaded_eq.data(), sizeof(af::ChainParams) * runs_eq.size(), hipMemcpyHostToDevice, es));
-          AF_HIP(hipStreamSynchronize(es));  // rare: the first window that qualifies
+          if (int rc2 = stage_upload(e, e->d_params_eq, runs_eq.data(), runs_eq.size(), es)) return rc2;
         }
         if (eq_needs_chain_done) {  // the previous window's EQ ran inside its chain launch: that launch owns the memories until it ends
           hipEvent_t chain_done;
@@ -1691,8 +1789,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         }
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
         AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
+        power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
         AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
-                                      rows_w, false, seg_n, stream_stride, e->n_streams, es));
+                                      rows_w, false, seg_n, stream_stride, e->n_streams, es, power_w));
         e->last_launches += 1;
         hipEvent_t eq_done;
         if (int rc2 = next_event(&eq_done)) return rc2;
@@ -1710,7 +1809,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (!diag_skip_chain)
       rc = launch_chain_segment(e, run_w, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
                                 e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream,
-                                eq_offloaded);
+                                eq_offloaded, power_w);
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);

@@ -167,6 +167,7 @@ struct LaunchArgs {
   BlockStats *stats;          // [blocks][n_streams]
   int32_t *status;            // device word: non-zero when a kernel gave up on a token (never expected)
   const BlockStats *pre_stats;  // rows of the pre-pass launch (compressor-input block power), or null
+  const double *pre_power;    // [blocks][n_streams] the same block power as a plain array (af_eq_systolic.hip as the pre-pass); wins over pre_stats
   const double *vad_prob;     // [blocks][n_streams] speech posteriors for auto-makeup, or null
   int64_t n_samples;
   int64_t stream_stride;

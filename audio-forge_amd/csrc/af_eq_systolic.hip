@@ -27,19 +27,26 @@
 
 namespace af {
 
-template <bool kStats, bool kXf>
+template <bool kStats, bool kXf, bool kPower = false>
 __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
-  eq_systolic_body<kStats, kXf>(a, blockIdx.x);
+  eq_systolic_body<kStats, kXf, kPower>(a, blockIdx.x);
 }
 
 // `audio`: stream-major output (may be `in`); or null and `ring` / `ring_in` / `ring_rows` / `n0`: the stage pipeline's rings.
 // `stats` null: no block input statistics.  `crossfade`: some section has a coefficient crossfade pending.
+// `block_power` ([block][stream], with `stats`): also the square sum of every control block of the filtered samples -- the
+// launch is then the pre-pass of an auto-makeup window.
 hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
-                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream) {
-  EqSystolicArgs a{d_params, d_group_preset, st64, in, audio, ring, ring_in, stats, n_samples, stream_stride, n0, n_streams, ring_rows};
+                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream, double *block_power) {
+  EqSystolicArgs a{d_params, d_group_preset, st64, in, audio, ring, ring_in, stats, n_samples, stream_stride, n0, n_streams, ring_rows,
+                   block_power};
   const dim3 grid((unsigned)((n_streams + 3) / 4)), block(64);
-  if (crossfade) {
+  if (block_power) {
+    if (!stats) return hipErrorInvalidValue;
+    if (crossfade) hipLaunchKernelGGL((eq_systolic_kernel<true, true, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((eq_systolic_kernel<true, false, true>), grid, block, 0, stream, a);
+  } else if (crossfade) {
     if (stats) hipLaunchKernelGGL((eq_systolic_kernel<true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((eq_systolic_kernel<false, true>), grid, block, 0, stream, a);
   } else {

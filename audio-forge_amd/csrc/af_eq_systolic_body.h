@@ -20,6 +20,7 @@ struct EqSystolicArgs {
   BlockStats *stats;            // [block][stream]: input_square_sum / input_sample_peak are written here (kStats)
   int64_t n_samples, stream_stride, n0;
   int32_t n_streams, ring_rows;
+  double *block_power;          // [block][stream]: sum of squares of the filtered samples of each control block (kPower), or null
 };
 
 template <int N>
@@ -34,8 +35,11 @@ __device__ __forceinline__ float row_shr1_keep(float keep, float v) {
 
 // kStats: lane 0 keeps the block input statistics.  kXf: a coefficient crossfade (biquad.rs:263-327) is pending for some
 // section at the start of the launch: every lane carries its pending filter beside the active one (general, slower form;
-// a stream opens with at most a few hundred such samples).
-template <bool kStats, bool kXf>
+// a stream opens with at most a few hundred such samples).  kPower: lane 15 keeps the square sum of every control block of
+// the FILTERED samples (f64, sample order, non-finite samples skipped: what the token-ring kernel's pre-pass launch leaves
+// in `output_square_sum`) -- the compressor-input block power the auto-makeup controller needs before the block's first
+// sample (compressor.rs:583-596,710), so this kernel is the whole pre-pass of an auto-makeup window.
+template <bool kStats, bool kXf, bool kPower = false>
 __device__ __forceinline__ void eq_systolic_body(const EqSystolicArgs &a, int block) {
   const int lane = threadIdx.x & 63;
   const int k = lane & 15;                      // section
@@ -104,6 +108,9 @@ __device__ __forceinline__ void eq_systolic_body(const EqSystolicArgs &a, int bl
   float in_peak = 0.0f;
   int64_t block_index = 0;
   int in_block = 0;      // samples of the current control block consumed so far (wave-uniform: streams advance in lock step)
+  double out_sq = 0.0;   // kPower: square sum of the current control block's filtered samples; only lane 15's is used
+  int64_t out_block_index = 0;
+  int out_in_block = 0;  // filtered samples of the current control block that have left lane 15 (wave-uniform)
 
   // Steps T = 16 g + j.  The sample leaving lane 15 at step T is sample u = T - 15 = 16 (g - 1) + j + 1: position j + 1 of
   // output group g - 1 for j < 15, position 0 of group g for j = 15.  So group G is complete after step (G + 1, 14) and is
@@ -192,6 +199,19 @@ __device__ __forceinline__ void eq_systolic_body(const EqSystolicArgs &a, int bl
         z2 = nz2;
       }
       y_prev = sec_lane ? (float)y : in;  // lanes past the last section pass their input on
+      if (kPower && (!kEdge || (T >= 15 && T - 15 < n))) {  // lane 15 has just produced filtered sample T - 15
+        const double yd = (double)y_prev;
+        out_sq += finite_f32(y_prev) ? yd * yd : 0.0;
+        if (kFlush) {
+          out_in_block += 1;
+          if (out_in_block == cb || T - 15 + 1 == n) {  // wave-uniform
+            if (k == 15 && valid) a.block_power[out_block_index * NS + s] = out_sq;
+            out_block_index += 1;
+            out_in_block = 0;
+            out_sq = 0.0;
+          }
+        }
+      }
       // ---- the sample leaving lane 15 now is sample T - 15 = position (j + 1) & 15 of its output group
       float leaving;
       switch (j) {  // lane (j + 1) & 15 <- lane 15: row_shl by 15 - ((j + 1) & 15)
@@ -223,14 +243,16 @@ __device__ __forceinline__ void eq_systolic_body(const EqSystolicArgs &a, int bl
       }
     }
     if (kStats && !kFlush) in_block += 16;
+    if (kPower && !kFlush) out_in_block += 16;
     x_cur = x_n1;
     x_n1 = x_n2;
     x_n2 = fetch(g + 3);
   };
   for (int64_t g = 0; g < groups + 1; ++g) {
     const int left = __builtin_amdgcn_readfirstlane(cb - in_block);  // samples to the end of the control block
+    const int left_out = kPower ? __builtin_amdgcn_readfirstlane(cb - out_in_block) : 32;  // ... on lane 15's side
     if (kXf || g < 1 || (g + 1) * 16 >= n) group(g, std::true_type{}, std::true_type{});  // (>=: a short last block ends at T + 1 == n)
-    else if (kStats && left <= 16) group(g, std::false_type{}, std::true_type{});
+    else if ((kStats && left <= 16) || (kPower && left_out <= 16)) group(g, std::false_type{}, std::true_type{});
     else group(g, std::false_type{}, std::false_type{});
   }
   // (group `groups - 1`, the last one, was stored by step 15 of the extra iteration g = groups)

@@ -21,6 +21,8 @@
 // in steady state the waves stagger themselves and nobody waits.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <type_traits>
 
 #include "af_dsp.h"
@@ -400,7 +402,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         {
           if (kAuto && first_in_block) {
             // estimate_auto_makeup_activity(block_rms_db(buffer), evidence), compressor.rs:528-596,710
-            const double power = a.pre_stats ? a.pre_stats[b * NS + sc].output_square_sum / (double)blk_len : 0.0;
+            const double power = a.pre_power   ? a.pre_power[b * NS + sc] / (double)blk_len
+                                 : a.pre_stats ? a.pre_stats[b * NS + sc].output_square_sum / (double)blk_len
+                                               : 0.0;
             const double brms_db = lin2db(sqrt(power), 1e-10);
             double absolute = 0.0;
             if (brms_db >= -55.0 && brms_db <= -6.0)
@@ -988,7 +992,17 @@ hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahe
 }
 // `dyn`: dynamic LDS of the launch (several presets: the largest of their layouts, every workgroup lays out its own)
 hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream) {
-  if (auto_makeup) return launch_variant<8, 4, true>(args, dyn, stream);  // one build: 256 VGPRs, no spills
+  if (auto_makeup) {
+    // AF_AUTO_WAVES=8|12|16 (same-box A/B): 8 waves hold everything in 235 VGPRs; 12 and 16 spill a little and keep more chunks
+    // in flight (the kernel is a closed queueing network of its waves)
+    static const int waves = [] {
+      const char *env = std::getenv("AF_AUTO_WAVES");
+      return env ? std::atoi(env) : 16;
+    }();
+    if (waves == 8) return launch_variant<8, 4, true>(args, dyn, stream);
+    if (waves == 12) return launch_variant<12, 4, true>(args, dyn, stream);
+    return launch_variant<16, 4, true>(args, dyn, stream);
+  }
   switch (variant) {
     case 1604: return launch_variant<16, 4>(args, dyn, stream);
     case 1602: return launch_variant<16, 2>(args, dyn, stream);

@@ -40,13 +40,14 @@ def local_metrics(rows: np.ndarray, samples: int, elapsed_s: float = 0.0) -> tup
 
 
 def reduce_metrics(sums: np.ndarray, maxes: np.ndarray, device=None) -> dict:
-    """The one collective of a run.  With no process group initialised it is the identity."""
+    """The one collective of a run.  With no process group initialised it is the identity; with one it runs even for a
+    single rank (bench.py --force-distributed executes the RCCL path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
     s = torch.as_tensor(np.asarray(sums, dtype=np.float64), device=device).clone()
     m = torch.as_tensor(np.asarray(maxes, dtype=np.float64), device=device).clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
     out = {k: float(v) for k, v in zip(SUM_KEYS, s.cpu().tolist())}

@@ -33,14 +33,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGORITHMIC_BYTES_PER_SAMPLE = 8  # 4 B f32 read + 4 B f32 write
 SAMPLE_RATE = 48_000
 
-CHAIN_SETTINGS = {  # python/tools/evaluate_limiter_lookahead.py:143-161 (BASELINE config 2 parameters)
-    "compressor_enabled": True, "compressor_threshold_db": -20.0, "compressor_ratio": 4.0,
-    "compressor_attack_ms": 10.0, "compressor_release_ms": 200.0, "compressor_makeup_gain_db": 0.0,
-    "compressor_adaptive_release": False, "compressor_auto_makeup_enabled": False,
-    "compressor_sidechain_highpass_enabled": True, "limiter_enabled": True, "limiter_ceiling_db": -0.5,
-    "limiter_release_ms": 50.0, "limiter_careful_output_enabled": True, "limiter_lookahead_ms": 2.0,
-}
-BANDS = [(80.0 * 1.75**k, 0.0, 1.0) for k in range(10)]
+def _chain_configuration():
+    """BASELINE config 2 parameters = the settings dict and bands `evaluation/limiter-lookahead-report.json` was rendered
+    with (2 ms lookahead): data captured from the reference's evaluator by tools/gen_golden.py (tests/golden/)."""
+    fixture = json.loads((ROOT / "tests" / "golden" / "limiter_lookahead.json").read_text())
+    settings = {k: v for k, v in fixture["settings"]["2"].items() if k not in ("return_output_audio", "deesser_enabled")}
+    return settings, [tuple(band) for band in fixture["bands"]]
+
+
+CHAIN_SETTINGS, BANDS = _chain_configuration()
 
 
 def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.device) -> torch.Tensor:
@@ -102,7 +103,7 @@ def _percentile(values, q: float) -> float:
     return float(v[lo] + (pos - lo) * (v[hi] - v[lo]))
 
 
-def cpu_baseline(seconds: float, full: bool) -> dict:
+def cpu_baseline(seconds: float, full: bool, chain_settings: dict | None = None) -> dict:
     """The CPU restatement of rust-core (oracle/, KAT-pinned; the Rust reference cannot be built offline) timed on this
     host, per SURVEY.md 8(d):
       single_thread: one S1 stream x `seconds`, 1 warm-up + 7 repetitions, median and p95
@@ -118,7 +119,7 @@ def cpu_baseline(seconds: float, full: bool) -> dict:
     import af_oracle_py as oracle  # the checker / baseline, never the product path
     from signals import kat_signal, stream_params
 
-    settings = dict(CHAIN_SETTINGS)
+    settings = dict(chain_settings or CHAIN_SETTINGS)
     lib = oracle.lib()
     ctypes.c_int.in_dll(lib, "afo_rnn_fft_mode").value = 1
 
@@ -269,6 +270,12 @@ def main() -> None:
     ap.add_argument("--chain", choices=["full", "dynamics"], default="full",
                     help="full = DC/HP prefilter + RNNoise + EQ + compressor + limiter + true-peak (configs[2]); "
                          "dynamics = EQ + compressor + limiter + true-peak only (configs[1] chain)")
+    ap.add_argument("--auto-makeup", action="store_true",
+                    help="compressor auto-makeup on (north_star's chain as literally named: per-block activity -> momentary "
+                         "loudness -> makeup, compressor.rs:598-653); target -16 LUFS")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the barrier and both metric all-reduces on device tensors "
+                         "even with one rank (RANK=0 WORLD_SIZE=1): executes the collective path on a one-GPU box")
     ap.add_argument("--stub-engine", action="store_true",
                     help="CPU rehearsal of the N-rank launch path: gloo ranks and a stub engine; not a measurement")
     args = ap.parse_args()
@@ -287,7 +294,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python bench.py --gpus N starts them itself; under torchrun pass --nproc-per-node N)")
@@ -306,7 +313,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         if args.stub_engine:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world)  # (CPU rehearsal of the launch / reduction path)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -331,7 +338,10 @@ def main() -> None:
     torch.cuda.synchronize()
 
     engine = core.Engine(SAMPLE_RATE, streams, local_rank)
-    core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, CHAIN_SETTINGS)
+    chain_settings = dict(CHAIN_SETTINGS)
+    if args.auto_makeup:
+        chain_settings.update(compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0)
+    core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, chain_settings)
     if not args.variant:
         engine.set_kernel(args.kernel)
     full = args.chain == "full"
@@ -374,6 +384,10 @@ def main() -> None:
     elapsed_max = merged["elapsed_s"]
     total_frames = int(merged["samples"])
     value = total_frames / elapsed_max
+    collective = None
+    if distributed:
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "calls": "barrier x2, all_reduce(SUM) + all_reduce(MAX) over a 14-double vector on the device"}
 
     used = int(engine._lib.af_engine_last_kernel(engine._h))
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
@@ -441,13 +455,15 @@ def main() -> None:
             "x_realtime": value / SAMPLE_RATE,
             "config": {
                 "workload": (f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, full chain: DC block + 80 Hz HP -> RNNoise "
-                             f"suppressor (synthetic weights) -> 10-band EQ -> compressor -> 2 ms lookahead limiter -> 4x true-peak "
-                             f"limiter/detector (BASELINE configs[2])") if full else
+                             f"suppressor (synthetic weights) -> 10-band EQ -> compressor{' with auto-makeup' if args.auto_makeup else ''} "
+                             f"-> 2 ms lookahead limiter -> 4x true-peak limiter/detector (BASELINE configs[2])") if full else
                             (f"batch={streams} streams/GPU x {args.seconds:g} s @48 kHz, 10-band EQ + compressor + 2 ms lookahead "
                              f"limiter + 4x true-peak limiter/detector, no suppressor (BASELINE configs[1] chain)"),
                 "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
                 "kernel": kernel_name, "sharding": f"streams x{world}, no data-path collective",
+                "auto_makeup": bool(args.auto_makeup),
             },
+            "collective": collective,
             "roofline": roofline,
             "stage_ms": {"suppressor_and_front_end": float(np.mean(supp_ms)), "chain": float(np.mean(chain_ms)),
                          "all_kernels": float(np.mean(kernel_ms))},
@@ -457,7 +473,7 @@ def main() -> None:
                        "true_peak_limited_blocks": int(merged["true_peak_limited_events"])},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is a single-GPU-run artefact (rank 0, N = 1)
-            line["cpu_baseline"] = cpu_baseline(args.seconds, full)
+            line["cpu_baseline"] = cpu_baseline(args.seconds, full, chain_settings)
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line))
@@ -475,7 +491,7 @@ def run_stub(args, world: int, rank: int, streams: int, n: int, first_stream: in
     engine = StubEngine(streams, n, first_stream)
 
     def barrier() -> None:
-        if world > 1:
+        if world > 1 or args.force_distributed:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -496,9 +512,10 @@ def run_stub(args, world: int, rank: int, streams: int, n: int, first_stream: in
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "STUB ENGINE (launch-path rehearsal on CPU, not a measurement)", "streams_per_gpu": streams,
                        "sharding": f"streams x{world}, no data-path collective"},
+            "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist.is_initialized() else None),
             "checks": {"total_samples": int(merged["samples"]), "input_square_sum": merged["input_square_sum"]},
         }))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

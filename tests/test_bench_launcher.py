@@ -45,3 +45,14 @@ def test_rank_count_must_agree_with_gpus():
     proc = _run(["--gpus", "1", "--stub-engine", "--steps", "1", "--warmup", "0"],
                 {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert proc.returncode != 0 and "WORLD_SIZE=2" in proc.stderr
+
+
+def test_force_distributed_runs_the_collectives_with_one_gloo_rank():
+    """--force-distributed: the process group, the barriers and both all-reduces run with a single rank (CPU rehearsal of
+    tests/test_gpu_rccl.py, which does the same on the MI355X over RCCL)."""
+    proc = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--streams", "8", "--seconds", "0.2", "--stub-engine",
+                 "--force-distributed"], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29731"})
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["collective"]["backend"] == "gloo" and line["collective"]["world_size"] == 1
+    assert line["checks"]["total_samples"] == 8 * 9600

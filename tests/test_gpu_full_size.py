@@ -27,11 +27,11 @@ def run():
     x = bench.synth_batch(STREAMS, SECONDS * 100, 0, dev)
     n = x.shape[1]
 
-    def process(full_chain: bool, streams=slice(None), trace: bool = False):
+    def process(full_chain: bool, streams=slice(None), trace: bool = False, settings=None):
         xin = x[streams].contiguous()
         y = torch.empty_like(xin)
         eng = core.Engine(48_000.0, xin.shape[0], 0)
-        core.configure_auto_eq_chain(eng, 48_000.0, bench.BANDS, bench.CHAIN_SETTINGS)
+        core.configure_auto_eq_chain(eng, 48_000.0, bench.BANDS, settings or bench.CHAIN_SETTINGS)
         if full_chain:
             eng.set_prefilter_enabled(1, 1)
             eng.set_suppressor_enabled(1)
@@ -46,23 +46,32 @@ def run():
     return x, process
 
 
-@pytest.mark.parametrize("full_chain", [False, True])
-def test_full_size_properties(run, oracle, full_chain):
+@pytest.mark.parametrize("mode", ["dynamics", "full", "full-automakeup"])
+def test_full_size_properties(run, oracle, mode):
+    """`full-automakeup` is north_star's chain as literally named (compressor WITH auto-makeup behind the suppressor): at this
+    batch every suppressor window takes the systolic EQ kernel as its pre-pass and one token-ring launch."""
     import torch
 
     import bench
 
     x, process = run
-    y, rows, decisions = process(full_chain, trace=True)
+    full_chain = mode != "dynamics"
+    settings = dict(bench.CHAIN_SETTINGS)
+    if mode == "full-automakeup":
+        settings.update(compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0)
+    y, rows, decisions = process(full_chain, trace=True, settings=settings)
     assert bool(torch.isfinite(y).all())
     # determinism: a second engine over the same input gives the same bits
-    y2, _ = process(full_chain)
+    y2, _ = process(full_chain, settings=settings)
     assert torch.equal(y, y2)
-    # stream independence: the same streams inside a batch of 70 (different workgroup / lane positions)
+    # stream independence: the same streams inside a batch of 70 (different workgroup / lane positions -- and at 70 streams
+    # AUTO runs the chain as the stage pipeline, whose arithmetic is the token-ring kernel's operation for operation)
     pick = [0, 1, 63, 64, 1000, 2047, 4032, 4095]
     sub = torch.tensor(pick + list(range(100, 162)), device=x.device)
-    y_sub, _ = process(full_chain, sub)
+    y_sub, _ = process(full_chain, sub, settings=settings)
     assert torch.equal(y_sub[: len(pick)], y[pick])
+    if mode == "full-automakeup":
+        assert float(rows["compressor_makeup_gain_db"].max()) > 1.0  # the controller really moved
     # energy bookkeeping: the block rows add up to the audio (f64 sums, f32 audio)
     out_sq = rows["output_square_sum"].sum(axis=0)
     direct = (y.double() ** 2).sum(dim=1).cpu().numpy()
@@ -83,12 +92,12 @@ def test_full_size_properties(run, oracle, full_chain):
             frames += pitch.size
         else:
             ref_in = xs
-        want = oracle.simulate_auto_eq_chain(ref_in, 48_000, bench.BANDS, dict(bench.CHAIN_SETTINGS, return_output_audio=True))["output_audio"]
+        want = oracle.simulate_auto_eq_chain(ref_in, 48_000, bench.BANDS, dict(settings, return_output_audio=True))["output_audio"]
         d = y[s].cpu().numpy().astype(np.float64) - want.astype(np.float64)
         rms = float(np.sqrt(np.mean(d * d)))
         worst_rms = max(worst_rms, rms)
         assert rms <= (1e-5 if full_chain else 2e-8), (s, rms)
-    print(f"full size ({'full' if full_chain else 'dynamics'} chain): {len(sample)} streams vs oracle, worst RMS {worst_rms:.3e}, "
+    print(f"full size ({mode} chain): {len(sample)} streams vs oracle, worst RMS {worst_rms:.3e}, "
           f"pitch decisions differing: {flips} of {frames} frames")
     if full_chain:
         assert flips <= frames // 1000

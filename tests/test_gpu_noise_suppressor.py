@@ -309,3 +309,60 @@ def test_gpu_against_the_scalar_order_oracle_with_pitch_decisions(mi, oracle):
         flips += int(np.count_nonzero(trace[:, k, 1] != pitch))
     print(f"pitch decisions differing GPU vs scalar-order oracle: {flips} of {250 * len(gains)} frames")
     assert flips <= 10
+
+
+def test_a_refused_call_leaves_the_frame_ring_untouched(mi):
+    """Everything that can refuse a call is checked before the engine's frame ring or a stream is touched (af_api.cpp,
+    af_engine_process_device): a call refused for its stride, or for a VAD array of the wrong length, leaves
+    af_engine_pending_input as it was, and the stream continues as if the call had not been made."""
+    import torch
+
+    from mic_eq_mi import _lib
+    from mic_eq_mi import mic_eq_core as core
+
+    x = torch.from_numpy(S.batch_signal(3, 6)).cuda()  # 2880 samples
+    settings = dict(S.limiter_settings(2.0), compressor_auto_makeup_enabled=True)
+
+    def engine():
+        e = core.Engine(48_000.0, 3)
+        core.configure_auto_eq_chain(e, 48_000.0, S.LIMITER_BANDS, settings)
+        e.set_suppressor_enabled(1)
+        e.set_control_block_samples(480)
+        return e
+
+    def run(e, lo, hi):
+        # (one stride serves both buffers: rows long enough for the frames this call may complete, pending ones included)
+        stride = (hi - lo) + 480
+        seg = torch.zeros((3, stride), dtype=torch.float32, device="cuda")
+        seg[:, : hi - lo] = x[:, lo:hi]
+        out = torch.zeros((3, stride), dtype=torch.float32, device="cuda")
+        e.process_device(seg.data_ptr(), out.data_ptr(), hi - lo, stride, 0, 0)
+        torch.cuda.synchronize()
+        n = e.last_output_samples()
+        return out[:, :n].cpu().numpy()
+
+    ref = engine()
+    want = np.concatenate([run(ref, 0, 400), run(ref, 400, 1500), run(ref, 1500, 2880)], axis=1)
+    ref.close()
+
+    e = engine()
+    a = run(e, 0, 400)
+    assert a.shape[1] == 0 and e.pending_input() == 400
+    # (1) this call would complete 1440 samples per stream but says its rows are only 1100 long
+    with pytest.raises(Exception) as err:
+        e.process_device(x.data_ptr(), x.data_ptr(), 1100, 1100, 0, 0)
+    assert "stream_stride" in str(err.value)
+    assert e.pending_input() == 400
+    # (2) auto-makeup evidence at the wrong cadence: 3 blocks will complete, 5 probabilities are offered
+    vad = np.full(5, 0.5)
+    _lib.check(e._lib.af_compressor_set_activity_evidence(e._h, vad.ctypes.data_as(C.POINTER(C.c_double)), 5, 0, 0.8, -60.0, 0.5))
+    with pytest.raises(Exception) as err:
+        run(e, 400, 1500)
+    assert "VAD" in str(err.value)
+    assert e.pending_input() == 400
+    _lib.check(e._lib.af_compressor_set_activity_evidence(e._h, None, 0, 0, 0.0, 1.0, 0.0))  # evidence off again
+    b = run(e, 400, 1500)
+    c = run(e, 1500, 2880)
+    e.close()
+    got = np.concatenate([a, b, c], axis=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

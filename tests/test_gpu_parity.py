@@ -149,6 +149,25 @@ def test_dynamics_aliasing_report_pins(mi, oracle):
         assert max_abs <= MAX_ABS and rms <= MAX_RMS, (name, max_abs, rms)
 
 
+def test_dynamics_aliasing_waveform_rows_from_the_gpu(mi):
+    """The aliasing report's waveform rows (`evaluation/dynamics-aliasing-report.json`: relative error between the 48 kHz
+    render and the 192 kHz render brought down to 48 kHz, and the folded-product energy) recomputed from GPU renders at both
+    rates: the published figures to 1e-4 dB (the GPU's libm differs from the reference's in the last bits of a few samples)."""
+    variant = os.environ.get("AF_KERNEL_VARIANT", "")
+    if not (variant.startswith("quad") or variant == "staged"):
+        pytest.skip("the 192 kHz render needs the 16-stream kernel or the stage pipeline (384-sample lookahead)")
+    published = {"carrier_8k": (-19.001835719980615, -43.454789994894405), "carrier_15k": (-25.511439358287017, -47.70959094355128)}
+    for name, carrier, mod in S.ALIASING_CASES:
+        if name not in published:
+            continue
+        renders = [np.asarray(mi.simulate_auto_eq_chain(S.aliasing_signal(fs, carrier, mod), fs, S.ALIASING_BANDS, S.ALIASING_SETTINGS)["output_audio"],
+                              dtype=np.float64) for fs in (48_000, 192_000)]
+        got = S.aliasing_case_metrics(renders[0], renders[1], carrier, mod)
+        assert got["alignment_lag_samples"] == 0
+        assert abs(got["relative_waveform_error_db"] - published[name][0]) <= 1e-4, (name, got)
+        assert abs(got["folded_out_of_expected_error_db"] - published[name][1]) <= 1e-4, (name, got)
+
+
 def test_dynamics_aliasing_report_pins_at_192_khz(mi, oracle):
     """The report's 192 kHz column (evaluation/dynamics-aliasing-report.json): the 2 ms lookahead is 384 samples there,
     which only the 16-stream kernel holds in LDS (AUTO routes to it; the 64-stream kernels refuse)."""

@@ -130,3 +130,46 @@ def test_ramped_window_schedule_matches_restatement(mi, oracle):
     want = np.stack([oracle.suppressor_process(audio[s], 1.0, 0x5EED) for s in range(audio.shape[0])])
     got = mi.suppress(audio, 1.0, 0x5EED)
     _check(got, want)
+
+
+@pytest.mark.parametrize("kernel,adaptive", [(0, False), (2, False), (2, True)], ids=["auto", "token-ring", "token-ring-adaptive"])
+def test_north_star_chain_with_auto_makeup_behind_the_suppressor(mi, oracle, kernel, adaptive):
+    """north_star's chain as literally named: DC block / 80 Hz high-pass -> RNNoise suppressor -> 10-band EQ -> compressor WITH
+    auto-makeup (compressor.rs:598-653,700-722: per-block activity -> momentary loudness -> makeup) -> lookahead limiter ->
+    true-peak limiter, in the realtime stage order (dsp_loop.rs:1222-1250).  70 streams (two chain workgroups, the second
+    ragged), two calls of several suppressor windows each, against oracle.suppressor_process o simulate_auto_eq_chain.
+    kernel 0 = AUTO (the stage pipeline at this batch), 2 = the token-ring kernel (what batch 4096 runs): its windows take
+    the systolic EQ kernel as their pre-pass (block powers) and ONE chain launch each."""
+    from mic_eq_mi import mic_eq_core as core
+
+    n_streams, frames_a, frames_b = 70, 130, 110
+    x = (S.batch_signal(n_streams, frames_a + frames_b) + np.float32(0.02)).astype(np.float32)
+    settings = dict(S.limiter_settings(2.0), compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0,
+                    compressor_adaptive_release=adaptive)
+    bands = list(S.LIMITER_BANDS)
+    bands[3] = (bands[3][0], 4.0, 1.2)
+    bands[7] = (bands[7][0], -3.0, 0.9)
+    eng = core.Engine(48_000.0, n_streams)
+    core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)
+    eng.set_prefilter_enabled(1, 1)
+    eng.set_suppressor_enabled(1)
+    eng.set_kernel(kernel)
+    a = eng.process(x[:, : frames_a * 480])
+    rows_a = eng.block_stats()
+    used = eng.last_kernel()
+    b = eng.process(x[:, frames_a * 480 :])
+    rows_b = eng.block_stats()
+    eng.close()
+    assert used == (4 if kernel == 0 else 2)
+    got = np.concatenate([a, b], axis=1)
+    makeup = np.concatenate([rows_a["compressor_makeup_gain_db"], rows_b["compressor_makeup_gain_db"]], axis=0)  # [block][stream]
+    worst = 0.0
+    for s in (0, 1, 63, 64, 69):
+        sup = oracle.suppressor_process(oracle.prefilter(x[s]), 1.0)
+        want = oracle.simulate_auto_eq_chain(sup, 48_000, bands, dict(settings))
+        d = got[s].astype(np.float64) - np.asarray(want["output_audio"], dtype=np.float64)
+        rms = float(np.sqrt(np.mean(d * d)))
+        worst = max(worst, rms)
+        assert rms <= 1e-5, (s, rms)
+        assert float(makeup[:, s].max()) > 1.0, s  # the controller really moved
+    print(f"north_star chain with auto-makeup (kernel {kernel}, adaptive {adaptive}): worst RMS vs oracle {worst:.3e}")

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Same-box A/B of the default bench step under environment switches: tools/full_ab.sh name:VAR=val[,VAR=val] ...
+# (BENCH_ARGS="--auto-makeup" adds arguments to every run)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for spec in "$@"; do
   name="${spec%%:*}"; vars="${spec#*:}"
-  env ${vars//,/ } python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "gpurun_out/full_${name}.json" 2> "gpurun_out/full_${name}.err"
+  env ${vars//,/ } python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > "gpurun_out/full_${name}.json" 2> "gpurun_out/full_${name}.err"
   python - "$name" <<'PY'
 import json, sys
 n = sys.argv[1]
