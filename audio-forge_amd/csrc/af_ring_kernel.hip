@@ -997,7 +997,7 @@ hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant
     // in flight (the kernel is a closed queueing network of its waves)
     static const int waves = [] {
       const char *env = std::getenv("AF_AUTO_WAVES");
-      return env ? std::atoi(env) : 16;
+      return env ? std::atoi(env) : 12;  // full bench step with auto-makeup, same box: 8 -> 276 ms, 12 -> 228, 16 -> 232 (plain chain: 203)
     }();
     if (waves == 8) return launch_variant<8, 4, true>(args, dyn, stream);
     if (waves == 12) return launch_variant<12, 4, true>(args, dyn, stream);

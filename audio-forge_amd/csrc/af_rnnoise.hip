@@ -1592,6 +1592,137 @@ extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_resynth_ker
   }
 }
 
+// Resynthesis and overlap-add as ONE kernel (round 3): a wave takes a stream through ALL frames of the window in order, so the
+// 960 windowed samples of a frame never leave the CU -- the first half meets the previous frame's second half (eight values
+// per lane, in registers; across windows: the stream's synthesis memory) and goes out as finished audio, the second half
+// waits in registers for the next frame.  Against the two-kernel form this removes the write of every windowed frame over its
+// P cell, its read (and the re-read of the previous frame's half) by supp_overlap_kernel, that kernel's launch and its
+// one-wave-per-stream walk: 10.5 KB of HBM traffic per frame and stream become 1.9 KB (the output) + 1.9 KB (the dry signal,
+// only when the mix needs it).  Arithmetic per sample is the two kernels' own, operation for operation.
+extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_synth_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ FftShared S;
+  __shared__ FftUnitLds U[kFftWaves];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  fft_shared_init(S, tb, tid, 64 * kFftWaves);
+  __syncthreads();
+  const int s = blockIdx.x * kFftWaves + wave;
+  if (s >= a.n_streams) return;
+  FftUnitLds &L = U[wave];
+  float *prod = L.prod();
+  float *rv = L.small(), *normv = rv + 32, *gv = rv + 64;  // band vectors the per-bin interpolation gathers from
+  float *st = a.state + (int64_t)s * SuppState::kCount;
+  float smoothed = st[SuppState::kSmoothedStrength];
+  float prev[8];  // the previous frame's second half: sample 480 + lane + 64 j
+#pragma unroll
+  for (int j = 0; j < 8; ++j) prev[j] = (lane + 64 * j) < kRnnFrame ? st[SuppState::kSynthMem + lane + 64 * j] : 0.0f;
+  const bool dry_from_out = a.front_clamp || a.front_dc;
+  for (int f = 0; f < a.n_frames; ++f) {
+    const int64_t cell = (int64_t)f * a.n_streams + s;
+    const SuppFrameRec *rec = a.rec + cell;
+    const float2 *Xg = a.X + cell * kRnnFreq;
+    const float2 *Pg = a.P + cell * kRnnFreq;
+    float2 Xr[8], Pr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      Xr[j] = i < kRnnFreq ? Xg[i] : make_float2(0.0f, 0.0f);
+      Pr[j] = i < kRnnFreq ? Pg[i] : make_float2(0.0f, 0.0f);
+    }
+    float Ex = 0.0f, Ep = 0.0f, Exp = 0.0f, g = 0.0f, graw = 0.0f;
+    if (lane < kRnnBands) {
+      Ex = rec->Ex[lane];
+      Ep = rec->Ep[lane];
+      Exp = rec->Exp[lane];
+      g = rec->gains[lane];
+      graw = rec->gains_raw[lane];
+    }
+    const bool silence = rec->silence != 0;
+    // wet/dry smoothing, rnnoise.rs:81-86 (once per frame); the dry samples travel while the frame is transformed
+    smoothed = a.strength * a.smoothing_coeff + smoothed * (1.0f - a.smoothing_coeff);
+    const bool mix = !a.raw_protocol && smoothed < 1.0f;
+    const int64_t base = (int64_t)s * a.stream_stride + (a.frame0 + f) * kRnnFrame;
+    if (!silence) {
+      // ---- pitch_filter (denoise.c): comb-filter the bands the network trusts less than the pitch
+      if (lane < kRnnBands) {
+        const float e = Exp;
+        float r;
+        if (e > graw) r = 1;
+        else r = e * e * (1 - graw * graw) / (.001f + graw * graw * (1 - e * e));
+        r = sqrtf(fminf(1.0f, fmaxf(0.0f, r)));
+        r *= sqrtf(Ex / (1e-8f + Ep));
+        rv[lane] = r;
+        gv[lane] = g;
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < kRnnFreq) {
+          const float rf = interp_gain(rv, S, i);
+          Xr[j].x += rf * Pr[j].x;
+          Xr[j].y += rf * Pr[j].y;
+          if (i < 400) prod[band_skew(i)] = Xr[j].x * Xr[j].x + Xr[j].y * Xr[j].y;
+        }
+      }
+      {
+        const float newE = band_sums_wave(prod, L.scratch(), S, lane);
+        if (lane < kRnnBands) normv[lane] = sqrtf(Ex / (1e-8f + newE));
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < kRnnFreq) {
+          const float nf = interp_gain(normv, S, i);
+          float2 v = Xr[j];
+          v.x *= nf;
+          v.y *= nf;
+          const float gf = interp_gain(gv, S, i);  // band gains after the lastg floor
+          v.x *= gf;
+          v.y *= gf;
+          Xr[j] = v;
+        }
+      }
+      wave_lds_fence();  // every gather from the band vectors is done: the transform buffer may be filled
+    }
+    // ---- frame_synthesis: inverse transform through the forward FFT of the Hermitian extension
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < kRnnFreq) {
+        L.fa[i] = Xr[j];
+        if (i > 0 && i < kRnnFrame) L.fa[kRnnWindow - i] = make_float2(Xr[j].x, -Xr[j].y);
+      }
+    }
+    wave_lds_fence();
+    fft960_wave(L.fa, S, lane, 1.0f);
+    float dry[8];  // (fetched behind the transform: in front of it the eight registers spill)
+    if (mix) {
+      const float *dp = dry_from_out ? a.out + base : a.in + (int64_t)s * a.in_stride + (a.frame0 + f) * kRnnFrame;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dry[j] = (lane + 64 * j) < kRnnFrame ? dp[lane + 64 * j] : 0.0f;
+    }
+    // ---- overlap-add (first half + the previous frame's second half), /32768, wet/dry mix (rnnoise.rs:81-160)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = lane + 64 * j;
+      if (i < kRnnFrame) {
+        const float y_first = L.fa[(kRnnWindow - i) % kRnnWindow].x * window_at(S, i);
+        const float y_second = L.fa[kRnnFrame - i].x * window_at(S, kRnnFrame + i);  // sample 480 + i sits at slot (960 - 480 - i)
+        float wet = (y_first + prev[j]) / 32768.0f;
+        if (mix) wet = (smoothed * wet) + ((1.0f - smoothed) * dry[j]);
+        a.out[base + i] = wet;
+        prev[j] = y_second;
+      }
+    }
+    wave_lds_fence();
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if ((lane + 64 * j) < kRnnFrame) st[SuppState::kSynthMem + lane + 64 * j] = prev[j];
+  if (lane == 0) st[SuppState::kSmoothedStrength] = smoothed;
+}
+
 // One wave per stream, frames in order: overlap-add of the windowed frames, /32768, smoothed wet/dry mix.
 extern "C" __global__ __launch_bounds__(64) void supp_overlap_kernel(SuppArgs a) {
   const int lane = threadIdx.x;
@@ -1707,8 +1838,16 @@ hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, 
     if (err != hipSuccess) return err;
     fin = finish_stream;
   }
-  hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64 * kFftWaves), 0, fin, a, tb);
-  hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, fin, a);
+  static const bool fused_synthesis = [] {  // AF_SYNTH_FUSED=0: resynthesis and overlap-add as two kernels (round 2; same-box A/B)
+    const char *env = std::getenv("AF_SYNTH_FUSED");
+    return !env || std::atoi(env) != 0;
+  }();
+  if (fused_synthesis) {
+    hipLaunchKernelGGL(supp_synth_kernel, dim3((unsigned)((a.n_streams + kFftWaves - 1) / kFftWaves)), dim3(64 * kFftWaves), 0, fin, a, tb);
+  } else {
+    hipLaunchKernelGGL(supp_resynth_kernel, dim3(cells), dim3(64 * kFftWaves), 0, fin, a, tb);
+    hipLaunchKernelGGL(supp_overlap_kernel, dim3(a.n_streams), dim3(64), 0, fin, a);
+  }
   return hipGetLastError();
 }
 

@@ -81,19 +81,61 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
 CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: max shader clock (the issue roof below is priced at it)
 
 
-def profile_counters(full: bool, streams: int, seconds: float):
-    """Counter figures of this workload from the committed rocprofv3 --pmc passes (profiles/r02_step_counters.json, written
-    by tools/step_counters.py from separate counter runs of this same command; counters cannot be read from inside a
-    timed run).  Returned only when the profile was taken at this shape; it carries the commit it was taken at."""
-    path = ROOT / "profiles" / "r02_step_counters.json"
-    try:
-        prof = json.loads(path.read_text())
-    except (OSError, ValueError):
+def profile_counters(full: bool, streams: int, seconds: float, auto_makeup: bool = False):
+    """Counter figures of this workload from the committed rocprofv3 --pmc passes (profiles/r*_*counters*.json, written by
+    tools/step_counters.py from separate counter runs of this same command; counters cannot be read from inside a timed
+    run).  The newest round's file taken at exactly this shape is used; it carries the commit it was taken at."""
+    best = None
+    for path in sorted((ROOT / "profiles").glob("r[0-9][0-9]_*counters*.json")):
+        try:
+            prof = json.loads(path.read_text())
+        except (OSError, ValueError):
+            continue
+        shape = prof.get("shape") or {}
+        if (shape.get("streams") == streams and shape.get("seconds") == seconds and shape.get("chain") == ("full" if full else "dynamics")
+                and bool(shape.get("auto_makeup", False)) == auto_makeup and "kernels" in prof):
+            prof["_file"] = f"profiles/{path.name}"
+            best = prof  # (sorted by name: the highest round wins)
+    return best
+
+
+F32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate), = the f32 vector peak
+RNN_LAYERS_MNK = [  # the network's contractions per frame, M = streams (SURVEY.md 8(d): ~86.9 k MAC = 174 kFLOP per frame per stream)
+    ("dense 42->24", 24, 42), ("GRU 24 <- 24+24", 72, 48), ("GRU 48 <- 90+48", 144, 138), ("GRU 96 <- 114+96", 288, 210),
+    ("dense 96->22", 22, 96),
+]
+
+
+def mfma_block(prof: dict, streams: int, frames: int) -> dict | None:
+    """roofline.mfma ("MFMA utilisation reported for that kernel alone ... with M/N/K shapes"): the RNNoise
+    network kernel's matrix-core figures from the counter passes of this workload."""
+    row = next((v for k, v in prof["kernels"].items() if "supp_rnn_kernel" in k), None)
+    if row is None:
         return None
-    shape = prof.get("shape", {})
-    if shape.get("streams") != streams or shape.get("seconds") != seconds or shape.get("chain") != ("full" if full else "dynamics"):
-        return None
-    return prof
+    sq = row.get("sq", {})
+    macs = sum(n * k for _name, n, k in RNN_LAYERS_MNK)
+    flops_step = 2.0 * macs * streams * frames
+    out = {
+        "kernel": "supp_rnn_kernel<4>", "instruction": "v_mfma_f32_16x16x4_f32 (exact f32 fma chains; bf16 operands would miss the 1e-5 budget)",
+        "shapes_MNK": [{"layer": name, "M": streams, "N": n, "K": k} for name, n, k in RNN_LAYERS_MNK],
+        "algorithmic_flops_per_step": flops_step, "launches_per_step": row["launches_per_step"],
+        "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+    }
+    wave_cycles = sq.get("SQ_WAVE_CYCLES")
+    busy = sq.get("SQ_VALU_MFMA_BUSY_CYCLES")
+    if busy is not None:
+        out["mfma_busy_cycles_per_step"] = busy
+        if wave_cycles:
+            out["mfma_busy_over_wave_lifetime"] = busy / (4.0 * wave_cycles)  # SQ_WAVE_CYCLES counts quad-cycles (guide)
+    if sq.get("SQ_INSTS_VALU_MFMA_MOPS_F32") is not None:
+        out["mfma_mops_f32_per_step"] = sq["SQ_INSTS_VALU_MFMA_MOPS_F32"]
+    if row.get("kernel_ms_per_launch"):
+        t = row["kernel_ms_per_launch"] * 1e-3 * row["launches_per_step"]
+        out["achieved"] = flops_step / t / 1e12
+        out["frac"] = out["achieved"] / F32_MATRIX_PEAK_TFLOPS
+        if busy is not None:
+            out["mfma_busy_frac_of_chip"] = busy / (t * CLOCK_HZ * 1024)  # 256 CUs x 4 SIMDs
+    return out
 
 
 def _percentile(values, q: float) -> float:
@@ -108,8 +150,9 @@ def cpu_baseline(seconds: float, full: bool, chain_settings: dict | None = None)
     host, per SURVEY.md 8(d):
       single_thread: one S1 stream x `seconds`, 1 warm-up + 7 repetitions, median and p95
                      (python/tools/evaluate_limiter_lookahead.py:28,288-289,319-323);
-      all_cores:     S3 batch of 256 streams x 2 s, one stream shard per host thread (ctypes releases the GIL),
-                     1 warm-up + 3 repetitions, median;
+      gpu_share_threads: S3 batch of 256 streams x 2 s, one stream shard per thread on the host cores that belong to ONE GPU's
+                     share of the box (min(sched_getaffinity, 16): a one-GPU box is given 16 of the host's cores; ctypes releases
+                     the GIL), 1 warm-up + 7 repetitions, median and p95 -- NOT the whole host (`host_cores` says how many it has);
       suppressor:    per-frame time percentiles of the RNNoise stage alone (bin/rnnoise_benchmark.rs:92-96).
     The RNNoise stage runs its packed mixed-radix transforms (afo_rnn_fft_mode = 1, same results to the last bits)."""
     import ctypes
@@ -163,14 +206,16 @@ def cpu_baseline(seconds: float, full: bool, chain_settings: dict | None = None)
 
         times = []
         with ThreadPoolExecutor(max_workers=threads) as pool:
-            for rep in range(4):
+            for rep in range(8):
                 t0 = time.perf_counter()
                 total = sum(pool.map(run_shard, shards))
                 if rep:
                     times.append(time.perf_counter() - t0)
-        multi = {"value": total / _percentile(times, 0.5), "unit": "frames/s", "cores": threads, "repetitions": 3,
-                 "median_s": _percentile(times, 0.5), "x_realtime": total / _percentile(times, 0.5) / SAMPLE_RATE,
-                 "sample": f"{batch} streams x {shard_blocks / 100:g} s (S3), one shard per thread, 1 warm-up + 3 repetitions"}
+        multi = {"value": total / _percentile(times, 0.5), "unit": "frames/s", "cores": threads, "repetitions": 7,
+                 "median_s": _percentile(times, 0.5), "p95_s": _percentile(times, 0.95),
+                 "x_realtime": total / _percentile(times, 0.5) / SAMPLE_RATE, "cores_available": available,
+                 "sample": f"{batch} streams x {shard_blocks / 100:g} s (S3), one shard per thread on {threads} threads "
+                           f"(one GPU's share of the host), 1 warm-up + 7 repetitions"}
         # ---- RNNoise stage per frame
         frame_stats = None
         if full:
@@ -204,7 +249,7 @@ def cpu_baseline(seconds: float, full: bool, chain_settings: dict | None = None)
         "value": multi["value"], "unit": "frames/s", "cores": multi["cores"], "kind": "port",
         "sample": multi["sample"] + f"; same chain ({'full' if full else 'dynamics'}); CPU restatement of rust-core (oracle/), "
                   "the Rust reference cannot be built offline",
-        "x_realtime": multi["x_realtime"], "single_thread": single, "all_cores": multi, "suppressor_per_frame": frame_stats,
+        "x_realtime": multi["x_realtime"], "single_thread": single, "gpu_share_threads": multi, "suppressor_per_frame": frame_stats,
         "host_cpu": cpu_model, "host_cores": os.cpu_count(),
     }
 
@@ -413,7 +458,7 @@ def main() -> None:
                                   "dependent-instruction latency of one wave per recurrence (~8 cycles per vector instruction, "
                                   "tools/probe/valu_latency.hip): a step lasts as long as its longest stage, the EQ"),
         }
-        prof = profile_counters(full, streams, args.seconds)
+        prof = profile_counters(full, streams, args.seconds, args.auto_makeup)
         if prof is not None:
             row = next((v for k, v in prof["kernels"].items() if kernel_name.split("<")[0] in k), None)
             if row is not None:
@@ -437,7 +482,9 @@ def main() -> None:
                 "algorithmic_bytes": ALGORITHMIC_BYTES_PER_SAMPLE * streams * n,
                 "per_kernel": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in prof["kernels"].items()},
             }
-            roofline["counters_from"] = {"file": "profiles/r02_step_counters.json", "commit": prof.get("commit"),
+            if full:
+                roofline["mfma"] = mfma_block(prof, streams, n // 480)
+            roofline["counters_from"] = {"file": prof["_file"], "commit": prof.get("commit"),
                                          "note": "separate rocprofv3 --pmc runs of this command; not measured in this run"}
         line = {
             "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain",

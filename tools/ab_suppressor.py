@@ -21,6 +21,7 @@ import signals as S
 import mic_eq_mi
 
 audio = S.batch_signal(52, 160)  # 52 streams: three full 16-stream groups + 4; 1.6 s = 3 windows + 10 frames
-out = mic_eq_mi.suppress(audio, 1.0, 0x5EED)
+strength = float(os.environ.get("AB_STRENGTH", "1.0"))  # < 1: the wet/dry mix path
+out = mic_eq_mi.suppress(audio, strength, 0x5EED)
 np.save(os.path.join(ROOT, "gpurun_out", f"ab_{sys.argv[1]}.npy"), out)
 print(sys.argv[1], float(np.sqrt(np.mean(out.astype(np.float64) ** 2))))

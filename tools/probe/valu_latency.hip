@@ -11,6 +11,7 @@ template <int kKind>
 __global__ __launch_bounds__(64) void chain(double *out, long long *cycles, double a, double b, float fa) {
   double x = a + threadIdx.x * 1e-9, y = b;
   float f = fa + threadIdx.x * 1e-6f, g = 0.5f;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < 16; ++it) {
     if (kKind == 0) { REP256(asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "v"(y));) }
@@ -30,21 +31,28 @@ __global__ __launch_bounds__(64) void chain(double *out, long long *cycles, doub
     }
   }
   const long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   out[threadIdx.x] = x + y + f + g;
-  if (threadIdx.x == 0) cycles[0] = t1 - t0;
+  if (threadIdx.x == 0) {
+    cycles[0] = t1 - t0;                 // s_memtime: shader cycles (MI355X_MICROARCH.md, "s_memtime tick = shader cycle")
+    cycles[1] = (long long)(r1 - r0);    // s_memrealtime: the constant 100 MHz counter
+  }
 }
 
 template <int kKind>
 void run(const char *name, int per_rep) {
   double *out; long long *cyc;
   hipMalloc(&out, 64 * sizeof(double));
-  hipMalloc(&cyc, sizeof(long long));
+  hipMalloc(&cyc, 2 * sizeof(long long));
   hipLaunchKernelGGL(chain<kKind>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0, 1.0000001, 1.0f);
   hipLaunchKernelGGL(chain<kKind>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0, 1.0000001, 1.0f);
-  long long h = 0;
-  hipMemcpy(&h, cyc, sizeof h, hipMemcpyDeviceToHost);
-  // s_memtime / readcyclecounter ticks at 100 MHz on this part: report raw ticks and ns per instruction instead
-  printf("%-34s %8lld ticks for %d instructions -> %.2f ns each\n", name, h, 16 * 256 * per_rep, h * 10.0 / (16.0 * 256 * per_rep));
+  long long h[2] = {0, 0};
+  hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
+  // readcyclecounter = s_memtime = shader cycles; the in-kernel clock is d(s_memtime) / d(s_memrealtime) x 100 MHz
+  const int n = 16 * 256 * per_rep;
+  const double ghz = h[1] > 0 ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+  printf("%-34s %8lld cycles for %d instructions -> %.2f cycles each = %.2f ns at the in-kernel clock of %.2f GHz\n", name, h[0], n,
+         (double)h[0] / n, ghz > 0 ? (double)h[0] / n / ghz : 0.0, ghz);
   hipFree(out); hipFree(cyc);
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold the per-group counter summaries of tools/step_counters.sh (gpurun_out/stepc_<n>.json) into
-profiles/r02_step_counters.json: per kernel and per bench STEP (the runs hold 1 warm-up + 1 timed step): launches, VALU
+gpurun_out/<round>_step_counters[_<shape>].json: per kernel and per bench STEP (the runs hold 1 warm-up + 1 timed step): launches, VALU
 wave-instructions, f64 flops, HBM fetch / write bytes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KB;
 on gfx950 FETCH_SIZE counts a 16-B-per-lane streaming read at half its bytes -- the chain kernel's float4 chunk loads --
 and is doubled for that kernel only; the suppressor's kernels read 4 and 8 B per lane, for which the counter is taken as
@@ -15,7 +15,7 @@ STEPS_IN_RUN = 2  # --warmup 1 --steps 1
 args = sys.argv[1:]
 chain = "dynamics" if "dynamics" in args else "full"
 merged: dict = {}
-for p in range(1, 5):
+for p in range(1, 6):
     path = ROOT / "gpurun_out" / f"stepc_{p}.json"
     if not path.exists():
         continue
@@ -23,6 +23,13 @@ for p in range(1, 5):
         row = merged.setdefault(name, {})
         for counter, v in counters.items():
             row[counter] = {"dispatches": v["dispatches"], "total": v["mean_per_dispatch"] * v["dispatches"]}
+durations = {}  # kernel name -> (average ms per launch, launches) from the counter-free pass
+stats_path = ROOT / "gpurun_out" / "stepc_kernel_stats.csv"
+if stats_path.exists():
+    import csv
+
+    for r in csv.DictReader(open(stats_path)):
+        durations[r["Name"]] = (float(r["AverageNs"]) / 1e6, int(r["Calls"]))
 kernels = {}
 for name, row in merged.items():
     def per_step(counter):
@@ -36,6 +43,7 @@ for name, row in merged.items():
                       + 2.0 * per_step("SQ_INSTS_VALU_FMA_F64"))
     kernels[name] = {
         "launches_per_step": launches,
+        "kernel_ms_per_launch": durations.get(name, (None, 0))[0],  # rocprofv3 --kernel-trace --stats, own run of the same command
         "fetch_bytes": (fetch_kb or 0.0) * 1024.0 * (2.0 if wide else 1.0),
         "fetch_correction": "x2 (16 B per lane streaming reads)" if wide else "none (4/8 B per lane reads: uncalibrated)",
         "write_bytes": (write_kb or 0.0) * 1024.0,
@@ -43,7 +51,8 @@ for name, row in merged.items():
         "f64_flops": f64 or 0.0,
         "sq": {c: per_step(c) for c in ("SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
                                         "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
-                                        "SQ_INSTS_VALU_MFMA_MOPS_F32") if c in row},
+                                        "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA",
+                                        "SQ_INSTS_VALU_MFMA_MOPS_F64", "GRBM_GUI_ACTIVE") if c in row},
     }
 try:
     commit = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -56,11 +65,17 @@ for i, a in enumerate(args):
     if a == "--seconds":
         seconds = float(args[i + 1])
 out = {
-    "_how": "tools/step_counters.sh: four separate `rocprofv3 --pmc <group> --kernel-trace` runs of `python bench.py --steps 1 --warmup 1 "
-            "--no-cpu-baseline` (FETCH_SIZE | WRITE_SIZE | SQ instruction counts | SQ activity), per-kernel totals divided by the 2 steps of a run",
-    "commit": commit or None, "shape": {"streams": streams, "seconds": seconds, "chain": chain}, "kernels": kernels,
+    "_how": "tools/step_counters.sh: five separate `rocprofv3 --pmc <group> --kernel-trace` runs of `python bench.py --steps 1 --warmup 1 "
+            "--no-cpu-baseline` (FETCH_SIZE | WRITE_SIZE | SQ instruction counts | SQ activity | matrix-core counters), per-kernel totals divided by the 2 steps of a run",
+    "commit": commit or None, "shape": {"streams": streams, "seconds": seconds, "chain": chain, "auto_makeup": "--auto-makeup" in args},
+    "kernels": kernels,
 }
-dest = ROOT / "gpurun_out" / "r02_step_counters.json"
+import os
+
+tag = os.environ.get("ROUND", "r03")
+suffix = "" if (chain, streams, "--auto-makeup" in args) == ("full", 4096, False) else (
+    f"_{chain}_{streams}" + ("_automakeup" if "--auto-makeup" in args else ""))
+dest = ROOT / "gpurun_out" / f"{tag}_step_counters{suffix}.json"
 dest.write_text(json.dumps(out, indent=1, sort_keys=True))
 total = sum(k["fetch_bytes"] + k["write_bytes"] for k in kernels.values())
 print(f"wrote {dest}: {len(kernels)} kernels, HBM traffic per step {total / 1e9:.2f} GB")
