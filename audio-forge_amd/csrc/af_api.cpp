@@ -44,6 +44,10 @@ hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_grou
                               float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
                               int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream,
                               double *block_power = nullptr);
+bool comp_roles_serves(const ChainParams &p);
+bool lim_roles_serves(const ChainParams &p);
+hipError_t launch_chain_comp_roles(const LaunchArgs &args, bool sidechain, bool adaptive, hipStream_t stream);
+hipError_t launch_chain_lim_roles(const LaunchArgs &args, int max_lookahead, hipStream_t stream);
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 }  // namespace af
 
@@ -144,6 +148,7 @@ struct af_engine {
   std::vector<Retired> retired;
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
   hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
+  hipStream_t lim_stream = nullptr;        // AF_ROLES=2: the limiter half of the chain (af_roles.hip) on CUs of its own
   hipStream_t eq_stream = nullptr;         // the window's systolic EQ (af_eq_systolic.hip), behind its overlap-add, beside the next window's synthesis
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
   af::BlockStats *d_stats_de = nullptr;    // rows of the de-esser pass
@@ -456,6 +461,17 @@ int check_device_status(af_engine *e) {
   return AF_OK;
 }
 
+// AF_ROLES (same-box A/B): 0 = AUTO never takes the role kernels; 1 = compressor and limiter both as role kernels;
+// 2 = the compressor stays on the token-ring kernel (which then ends at the compressor's output) and the limiter half runs as
+// the role kernel -- behind the suppressor on a stream and CUs of its own, one window behind the compressor.
+int roles_mode() {
+  static const int mode = [] {
+    const char *env = std::getenv("AF_ROLES");
+    return env ? std::atoi(env) : 0;
+  }();
+  return mode;
+}
+
 // after a launch of n samples: advance the (stream-uniform) crossfade counters
 void advance_crossfades(af_engine *e, int64_t n) {
  for (int preset = 0; preset <= (int)e->extra_presets.size(); ++preset) {
@@ -540,6 +556,8 @@ int launch_chain_multi(af_engine *e, uint32_t strip, uint32_t add, const float *
   return AF_OK;
 }
 
+int engine_event(af_engine *e, hipEvent_t *out_ev);
+
 // One pass of the chain over a segment of samples for every stream: one launch, or the pre-pass + main
 // pair when the compressor's auto-makeup needs whole-block input power first (compressor.rs:710).
 // `params_stream` is where parameter uploads are ordered; `stream` is where the kernels run.
@@ -564,7 +582,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   const bool quad_ok = !auto_makeup && !eq_first_deesser &&
                        af::quad_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, any_xf) <= af::kMaxLdsBytes;
   int kernel = e->kernel;
-  if (kernel == AF_KERNEL_AUTO) {
+  if (kernel == AF_KERNEL_AUTO || kernel == AF_KERNEL_ROLES) {
     // Kernel 2 (the token ring, 64 streams per workgroup) wherever its LDS fits: a launch lasts as long as ONE
     // workgroup needs for its streams' samples, whatever the batch, and since its waves carry priorities (in a serial
     // unit, and growing with the age of their chunk) that is shorter than kernel 3's (16 streams per workgroup, which
@@ -588,6 +606,88 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   const bool two_pass = (auto_makeup && !pre_power) || (deesser && eq_first);
   if (two_pass && kernel != AF_KERNEL_PHASED)
     return fail(AF_ERR_UNSUPPORTED, "EQ-before-de-esser order is only built around the token-ring kernel");
+  // ---- the role pipeline (af_roles.hip): compressor and limiter as two kernels of dedicated serial waves + feed-forward
+  // waves, LDS hand-over; the EQ and the block input statistics are the systolic EQ kernel's.  Where it serves the
+  // configuration it replaces the token-ring launch (same state planes: the two can alternate mid-stream).
+  {
+    const int roles_env = roles_mode();
+    const bool input_done = (run.flags & af::kFlagInputDone) != 0;
+    const bool eq_pre_ok = layout == AF_LAYOUT_STREAM_MAJOR && !(run.flags & (af::kFlagDcBlock | af::kFlagPreHighpass)) &&
+                           (!(run.flags & af::kFlagEq) || run.n_eq_sections <= 16);
+    const bool comp_on = (run.flags & af::kFlagCompressor) != 0;
+    const bool served = !two_pass && !deesser && !auto_makeup && af::lim_roles_serves(run) && (!comp_on || af::comp_roles_serves(run)) &&
+                        (input_done || eq_pre_ok);
+    if (served && (e->kernel == AF_KERNEL_ROLES || (e->kernel == AF_KERNEL_AUTO && roles_env != 0))) {
+      // the limiter half on a stream of its own (the suppressor pipeline's: other CUs, a window behind the compressor)
+      const hipStream_t lim_stream = (e->lim_stream && stream == e->aux_stream) ? e->lim_stream : stream;
+      e->last_kernel_used = AF_KERNEL_ROLES;
+      // AF_ROLES=2: the compressor stays on the token-ring kernel, which then ends at the compressor's output
+      const bool ring_comp = comp_on && roles_env == 2 && ring_fits;
+      af::ChainParams up = run;
+      if (ring_comp) up.flags = (up.flags & ~af::kFlagLimiter) | af::kFlagCompOnly;
+      if (!e->uploaded_valid || std::memcmp(&e->uploaded, &up, sizeof up) != 0) {
+        e->uploaded = up;
+        if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
+        e->uploaded_valid = true;
+      }
+      hipEvent_t t0 = nullptr, t1 = nullptr;
+      if (e->timing) {
+        AF_HIP(hipEventCreate(&t0));
+        AF_HIP(hipEventCreate(&t1));
+        AF_HIP(hipEventRecord(t0, stream));
+      }
+      if (!stats_cleared) AF_HIP(hipMemsetAsync(stats, 0, sizeof(af::BlockStats) * rows, stream));
+      af::LaunchArgs ra{};
+      ra.st64 = e->d_st64;
+      ra.st32 = e->d_st32;
+      ra.in = in;
+      ra.out = out;
+      ra.stats = stats;
+      ra.status = e->d_status;
+      ra.params = e->d_params;
+      ra.n_samples = n_samples;
+      ra.stream_stride = stream_stride;
+      ra.samples_before = samples_before;
+      ra.n_streams = e->n_streams;
+      ra.layout = layout;
+      if (!input_done) {  // EQ (or a plain pass when it is off) + block input statistics
+        AF_HIP(af::launch_eq_systolic(e->d_params, nullptr, e->d_st64, in, out, nullptr, nullptr, 0, 0, stats, any_xf, n_samples,
+                                      stream_stride, e->n_streams, stream));
+        ra.in = out;
+        e->last_launches += 1;
+      }
+      if (ring_comp) {
+        af::ChainParams shape = up;
+        shape.flags = (shape.flags & ~af::kFlagEq) | af::kFlagInputDone;  // (the systolic EQ kernel above did both)
+        if (std::memcmp(&e->uploaded, &shape, sizeof shape) != 0) {
+          e->uploaded = shape;
+          if (int rc = stage_upload(e, e->d_params, &e->uploaded, 1, stream)) return rc;
+        }
+        AF_HIP(af::launch_chain_ring(ra, shape.n_eq_sections, shape.lim.lookahead_samples, any_xf, e->ring_variant, false, stream));
+        ra.in = out;
+        e->last_launches += 1;
+      } else if (comp_on) {
+        AF_HIP(af::launch_chain_comp_roles(ra, run.comp.sidechain_highpass_enabled != 0, run.comp.adaptive_release != 0, stream));
+        ra.in = out;
+        e->last_launches += 1;
+      }
+      if (e->timing) {  // (with the limiter on its own stream the bracket holds what the chain stream did)
+        AF_HIP(hipEventRecord(t1, stream));
+        e->chain_ms_events.push_back({t0, t1});
+      }
+      if (lim_stream != stream) {
+        hipEvent_t comp_done;
+        if (int rc = engine_event(e, &comp_done)) return rc;
+        AF_HIP(hipEventRecord(comp_done, stream));
+        AF_HIP(hipStreamWaitEvent(lim_stream, comp_done, 0));
+      }
+      AF_HIP(af::launch_chain_lim_roles(ra, run.lim.lookahead_samples, lim_stream));
+      e->last_launches += 1;
+      advance_crossfades(e, n_samples);
+      return AF_OK;
+    }
+    if (e->kernel == AF_KERNEL_ROLES) kernel = ring_fits ? AF_KERNEL_PHASED : (quad_ok ? AF_KERNEL_QUAD : AF_KERNEL_LANE_PER_STREAM);  // not served: as AUTO
+  }
   af::LaunchArgs a{};
   a.st64 = e->d_st64;
   a.st32 = e->d_st32;
@@ -1041,6 +1141,7 @@ void af_engine_destroy(af_engine *e) {
   for (hipEvent_t ev : e->sync_events) (void)hipEventDestroy(ev);
   for (auto &pr : e->chain_ms_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = nullptr;
+  if (e->lim_stream) (void)hipStreamDestroy(e->lim_stream);
   if (e->fin_stream) (void)hipStreamDestroy(e->fin_stream);
   if (e->eq_stream) (void)hipStreamDestroy(e->eq_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
@@ -1269,7 +1370,7 @@ int af_engine_assign_presets(af_engine *e, const int32_t *preset_of_group, int32
 
 int af_engine_set_kernel(af_engine *e, int32_t kernel) {
   if (!e) return fail(AF_ERR_INVALID_ARGUMENT, "engine is null");
-  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_STAGED) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+  if (kernel < AF_KERNEL_AUTO || kernel > AF_KERNEL_ROLES) return fail(AF_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
   e->kernel = kernel;
   return AF_OK;
 }
@@ -1567,9 +1668,19 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (chain_cus * 2 > total_cus) chain_cus = 0;  // a chain that wants half the chip or more shares all of it
     }
     if (chain_cus > 0) {
-      std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u);
-      for (int bit = 0; bit < total_cus; ++bit) (bit < chain_cus ? chain_mask : rest_mask)[bit >> 5] |= 1u << (bit & 31);
+      // AF_ROLES=2: the limiter half of the chain gets CUs of its own (AF_LIM_CUS, default as many as the chain), taken from
+      // the suppressor's share
+      int lim_cus = 0;
+      if (roles_mode() == 2) {
+        const char *lenv = std::getenv("AF_LIM_CUS");
+        lim_cus = lenv ? std::atoi(lenv) : chain_cus;
+        if (lim_cus < 0 || chain_cus + lim_cus + 32 > total_cus) lim_cus = 0;
+      }
+      std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u), lim_mask(total_cus / 32, 0u);
+      for (int bit = 0; bit < total_cus; ++bit)
+        (bit < chain_cus ? chain_mask : (bit < chain_cus + lim_cus ? lim_mask : rest_mask))[bit >> 5] |= 1u << (bit & 31);
       hipError_t err = hipExtStreamCreateWithCUMask(&e->aux_stream, (uint32_t)chain_mask.size(), chain_mask.data());
+      if (err == hipSuccess && lim_cus > 0) err = hipExtStreamCreateWithCUMask(&e->lim_stream, (uint32_t)lim_mask.size(), lim_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
@@ -1577,7 +1688,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->eq_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream, &e->lim_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -1604,7 +1715,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     const char *env = std::getenv("AF_EQ_OFFLOAD");
     return !env || std::atoi(env) != 0;
   }();
-  const bool eq_offload = eq_offload_env && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) &&
+  const bool eq_offload = eq_offload_env && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED || e->kernel == AF_KERNEL_ROLES) &&
                           (e->ring_variant == 0 || e->ring_variant == 1604) && (run.flags & af::kFlagEq);
   bool eq_needs_chain_done = true;  // (the previous call's last chain launch has ended: the caller's stream waited for it)
   const bool auto_makeup_call = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
@@ -1625,18 +1736,29 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (syn != stream) AF_HIP(hipStreamWaitEvent(syn, ev, 0));
     if (fin && fin != stream) AF_HIP(hipStreamWaitEvent(fin, ev, 0));
     if (e->eq_stream != stream) AF_HIP(hipStreamWaitEvent(e->eq_stream, ev, 0));
+    if (e->lim_stream) AF_HIP(hipStreamWaitEvent(e->lim_stream, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
+  // Pipeline depth.  The spectrum / record buffers of window w are free again when its synthesis has ended, and the synthesis
+  // of w needs the analysis of w: with D buffer sets the loop analysis(w + D) <- synthesis(w) <- network(w) <- pitch spectra(w)
+  // <- analysis(w) bounds the window period by (sum of those kernels) / D.  Round 2 ran D = 2 (the trace showed exactly that
+  // period: 7.3 ms of dependent kernels per two windows); AF_SUPP_DEPTH=2 restores it for A/B runs.
+  static const int depth = [] {
+    const char *env = std::getenv("AF_SUPP_DEPTH");
+    const int d = env ? std::atoi(env) : af::SuppressorHost::kSpecBuffers;
+    return d < 2 ? 2 : (d > af::SuppressorHost::kSpecBuffers ? af::SuppressorHost::kSpecBuffers : d);
+  }();
+  const int ana_ahead = depth - 1, pre_ahead = depth;  // windows the analysis / the pre-pass run ahead of the synthesis
   auto window_args = [&](int64_t f0, int64_t nf, int64_t index) {
     af::SuppArgs sa{};
     sa.in = src;
     sa.in_stride = src_stride;
     sa.out = out;
     sa.xh = e->supp.d_xh + (size_t)(index % kXh) * e->supp.xh_floats;
-    sa.X = e->supp.d_X + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
-    sa.P = e->supp.d_P + (size_t)(index & 1) * e->supp.ws_cells * af::kRnnFreq;
+    sa.X = e->supp.d_X + (size_t)(index % depth) * e->supp.ws_cells * af::kRnnFreq;
+    sa.P = e->supp.d_P + (size_t)(index % depth) * e->supp.ws_cells * af::kRnnFreq;
     sa.ds = e->supp.d_ds;
-    sa.rec = e->supp.d_rec + (size_t)(index & 1) * e->supp.ws_cells;
+    sa.rec = e->supp.d_rec + (size_t)(index % depth) * e->supp.ws_cells;
     sa.state = e->supp.d_state;
     sa.stream_stride = stream_stride;
     sa.n_streams = e->n_streams;
@@ -1681,7 +1803,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   auto enqueue_ana = [&](int64_t w) -> int {
     const int64_t f0 = win_f0[w], nf = win_nf[w];
     AF_HIP(hipStreamWaitEvent(e->ana_stream, pre_done[w], 0));
-    if (w >= 2) AF_HIP(hipStreamWaitEvent(e->ana_stream, syn_done[w - 2], 0));  // its spectrum / record buffers are free
+    if (w >= depth) AF_HIP(hipStreamWaitEvent(e->ana_stream, syn_done[w - depth], 0));  // its spectrum / record buffers are free
     static const bool order_pitch = [] {  // AF_ORDER_PITCH=1: hold the pitch search back until the previous window's network ran
       const char *env = std::getenv("AF_ORDER_PITCH");
       return env && std::atoi(env) != 0;  // off: it only moves the starvation to the resynthesis kernel (313 vs 296 ms)
@@ -1691,13 +1813,14 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));
     return AF_OK;
   };
-  for (int64_t w = 0; w < std::min<int64_t>(2, n_windows); ++w)
+  for (int64_t w = 0; w < std::min<int64_t>(pre_ahead, n_windows); ++w)
     if (int rc = enqueue_pre(w)) return rc;
-  if (int rc = enqueue_ana(0)) return rc;
+  for (int64_t w = 0; w < std::min<int64_t>(ana_ahead, n_windows); ++w)
+    if (int rc = enqueue_ana(w)) return rc;
   for (int64_t w = 0; w < n_windows; ++w) {
     const int64_t f0 = win_f0[w], nf = win_nf[w];
     AF_HIP(hipStreamWaitEvent(syn, ana_done[w], 0));
-    if (fin && fin != syn && w >= 2) AF_HIP(hipStreamWaitEvent(syn, syn_done[w - 2], 0));  // its pitch-spectrum buffer is free
+    if (fin && fin != syn && w >= depth) AF_HIP(hipStreamWaitEvent(syn, syn_done[w - depth], 0));  // its pitch-spectrum buffer is free
     AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w], fin));
     if (e->trace) {  // the window's (silence, pitch index) decisions, before its record buffer is handed back to the analysis
       const af::SuppArgs sa = window_args(f0, nf, w);
@@ -1707,10 +1830,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     AF_HIP(hipEventRecord(syn_done[w], (fin && fin != syn) ? fin : syn));
     e->last_launches += 7;
-    if (w + 2 < n_windows)
-      if (int rc = enqueue_pre(w + 2)) return rc;
-    if (w + 1 < n_windows)
-      if (int rc = enqueue_ana(w + 1)) return rc;
+    if (w + pre_ahead < n_windows)
+      if (int rc = enqueue_pre(w + pre_ahead)) return rc;
+    if (w + ana_ahead < n_windows)
+      if (int rc = enqueue_ana(w + ana_ahead)) return rc;
     const int64_t seg0 = f0 * af::kRnnFrame, seg_n = nf * af::kRnnFrame;
     const double *vad = e->has_evidence ? e->d_vad + blocks_done * e->n_streams : nullptr;
     static const bool diag_skip_chain = std::getenv("AF_DIAG_SKIP_CHAIN") != nullptr;  // timing experiments only
@@ -1822,6 +1945,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (int rc = next_event(&ev)) return rc;
     AF_HIP(hipEventRecord(ev, e->aux_stream));
     AF_HIP(hipStreamWaitEvent(stream, ev, 0));
+    if (e->lim_stream) {
+      if (int rc = next_event(&ev)) return rc;
+      AF_HIP(hipEventRecord(ev, e->lim_stream));
+      AF_HIP(hipStreamWaitEvent(stream, ev, 0));
+    }
   }
   if (e->pipe.active && !diag_wins.empty()) {
     const hipStream_t ds = e->pipe.stream;

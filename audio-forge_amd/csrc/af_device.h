@@ -98,6 +98,8 @@ enum ChainFlags : uint32_t {
   kFlagPreHighpass = 1u << 8,
   kFlagPrePass = 1u << 9,      // first of two launches: front end + EQ only, no detector, no compressor bookkeeping
   kFlagInputDone = 1u << 10,   // the input unit's work (block input statistics) was done by another kernel (af_eq_systolic.hip)
+  kFlagCompOnly = 1u << 11,    // the launch ends at the compressor's output: limiter, true-peak limiter, output statistics and
+                               // detector belong to another kernel (af_roles.hip), which owns their state rows
 };
 
 struct ChainParams {

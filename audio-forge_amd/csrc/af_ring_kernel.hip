@@ -158,7 +158,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
 #define L64(row) l64[(row)*kLanes + lane]
 #define L32(row) l32[(row)*kLanes + lane]
 
-  const bool out_detector = !(flags & kFlagPrePass);  // this launch runs the output-side detector
+  const bool comp_only = (flags & kFlagCompOnly) != 0;  // the launch ends at the compressor's output (the host strips kFlagLimiter too)
+  const bool out_detector = !(flags & kFlagPrePass) && !comp_only;  // this launch runs the output-side detector
   const int tid = threadIdx.x;
   const int lane = tid & (kLanes - 1);
   const int wave = tid / kLanes;
@@ -770,6 +771,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       }
 
       // ---- token: true-peak gain (true_peak.rs:341-374), chain output, block output stats
+      if (!comp_only) {
       token_wait(turn, kTokTp, q);
       {
         double out_sq = first_in_block ? 0.0 : L64(kR64OutSq);
@@ -833,6 +835,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         }
       }
       token_pass(turn, kTokTp, q);
+      }
 
       // ---- feed-forward: store the chunk, output-side 4x true peak (the detector of block_processor.rs:159)
       if (vec_ok && kFull) {
@@ -909,9 +912,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
     const Map head64[] = {{kR64ScPrevIn, kCompScPrevIn}, {kR64ScPrevOut, kCompScPrevOut}, {kR64LowEnv, kCompLowEnv},
                           {kR64VoicedEnv, kCompVoicedEnv}, {kR64PresenceEnv, kCompPresenceEnv}, {kR64Plosive, kCompPlosive},
                           {kR64PeakEnvDb, kCompPeakEnvDb}, {kR64RmsEnvSq, kCompRmsEnvSq}};
-    const Map tail64[] = {{kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv}, {kR64SlowEnv, kCompSlowEnv},
+    const Map tail64[] = {{kR64LimGain, kLimGain},  // (first: skipped when another kernel owns the limiter)
+                          {kR64Gr, kCompGr}, {kR64FastEnv, kCompFastEnv}, {kR64SlowEnv, kCompSlowEnv},
                           {kR64CurReleaseMs, kCompCurReleaseMs}, {kR64TargetReleaseMs, kCompTargetReleaseMs},
-                          {kR64SmoothedMakeup, kCompSmoothedMakeup}, {kR64LimGain, kLimGain},
+                          {kR64SmoothedMakeup, kCompSmoothedMakeup},
                           {kR64ActScore, kCompActivityScore}, {kR64ActReliab, kCompActivityReliability},
                           {kR64CurrentLufs, kCompCurrentLufs}};
     constexpr int n_head64 = (int)(sizeof(head64) / sizeof(head64[0])), n_tail64 = (int)(sizeof(tail64) / sizeof(tail64[0]));
@@ -930,7 +934,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
       }
     }
     {  // rows of the tokens from the gain-reduction smoothing on
-      for (int k = wave; k < n_tail64; k += kRingWaves) a.st64[(int64_t)tail64[k].field * NS + s] = L64(tail64[k].row);
+      for (int k = wave; k < n_tail64; k += kRingWaves)
+        if (k > 0 || !comp_only) a.st64[(int64_t)tail64[k].field * NS + s] = L64(tail64[k].row);
       if (wave == 1 % kRingWaves && kAuto && P.comp.meter_slots > 0) {
         const int mbase = kF64Fixed + 4 * P.n_eq_sections;
         a.st64[(int64_t)(mbase + kMeterV1) * NS + s] = L64(kR64MeterV1);
@@ -943,11 +948,13 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         a.st64[(int64_t)kCompReleaseCoeff * NS + s] =
             P.comp.adaptive_release ? exp(-1.0 / (tau * P.comp.sample_rate)) : L64(kR64ReleaseCoeff);
         if (!(flags & kFlagCompressor)) a.st64[(int64_t)kCompGr * NS + s] = 0.0;
-        a.st32[(int64_t)kTpGain * NS + s] = L32(kR32TpGain);
-        a.st32[(int64_t)kLimPrefix * NS + s] = L32(kR32LimPrefix);
+        if (!comp_only) {
+          a.st32[(int64_t)kTpGain * NS + s] = L32(kR32TpGain);
+          a.st32[(int64_t)kLimPrefix * NS + s] = L32(kR32LimPrefix);
+        }
       }
       const int64_t n_end = n0 + a.n_samples;
-      for (int r = wave; r < kTpTaps; r += kRingWaves) {
+      for (int r = wave; r < (comp_only ? 0 : kTpTaps); r += kRingWaves) {
         const int rowi = (int)((n_end - kTpTaps + r) & (kTpRing - 1));
         a.st32[(int64_t)(kTpInHist + r) * NS + s] = L32(kR32Tpi + rowi);
         if (out_detector) a.st32[(int64_t)(kTpOutHist + r) * NS + s] = L32(kR32Tpo + rowi);

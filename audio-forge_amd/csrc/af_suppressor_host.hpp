@@ -80,7 +80,8 @@ struct SuppressorHost {
   float *d_state = nullptr;  // [streams][SuppState::kCount]
   float *d_xh = nullptr;
   float *d_ds = nullptr;
-  static constexpr int kXhBuffers = 3;
+  static constexpr int kXhBuffers = 4;    // model-input buffers: the pre-pass runs up to three windows ahead of the synthesis
+  static constexpr int kSpecBuffers = 3;  // spectrum / pitch-spectrum / record buffers: the analysis runs up to two windows ahead
   size_t xh_floats = 0;  // floats per model-input buffer
   size_t ws_cells = 0;   // (frame, stream) cells per spectrum / record buffer
   float2 *d_X = nullptr, *d_P = nullptr;
@@ -252,9 +253,9 @@ struct SuppressorHost {
     xh_floats = (size_t)n_streams * (kPitchBuf + (size_t)frames * kRnnFrame);
     ws_cells = cells;
     if ((err = hipMalloc(&d_xh, sizeof(float) * kXhBuffers * xh_floats)) != hipSuccess) return err;
-    if ((err = hipMalloc(&d_X, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
-    if ((err = hipMalloc(&d_P, sizeof(float2) * 2 * cells * kRnnFreq)) != hipSuccess) return err;
-    if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * 2 * cells)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_X, sizeof(float2) * kSpecBuffers * cells * kRnnFreq)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_P, sizeof(float2) * kSpecBuffers * cells * kRnnFreq)) != hipSuccess) return err;
+    if ((err = hipMalloc(&d_rec, sizeof(SuppFrameRec) * kSpecBuffers * cells)) != hipSuccess) return err;
     if ((err = hipMalloc(&d_ds, sizeof(float) * cells * (kPitchBuf / 2))) != hipSuccess) return err;
     ws_frames = frames;
     ws_streams = n_streams;

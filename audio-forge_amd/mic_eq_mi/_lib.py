@@ -24,7 +24,7 @@ AF_ERR_UNSUPPORTED = -5
 
 LAYOUT_STREAM_MAJOR = 0
 LAYOUT_TIME_MAJOR = 1
-KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD, KERNEL_STAGED = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_LANE_PER_STREAM, KERNEL_PHASED, KERNEL_QUAD, KERNEL_STAGED, KERNEL_ROLES = 0, 1, 2, 3, 4, 5
 
 
 class EqBandConfig(C.Structure):

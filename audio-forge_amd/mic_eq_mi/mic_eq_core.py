@@ -65,7 +65,7 @@ class Engine:
         self.device = int(device)
 
     def _apply_variant_override(self) -> None:
-        """AF_KERNEL_VARIANT=lane | quad | staged | ring-<waves>x<chunk> pins the kernel (tests and tuning runs)."""
+        """AF_KERNEL_VARIANT=lane | quad | staged | roles | ring-<waves>x<chunk> pins the kernel (tests and tuning runs)."""
         import os
 
         variant = os.environ.get("AF_KERNEL_VARIANT", "")
@@ -73,6 +73,8 @@ class Engine:
             _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_LANE_PER_STREAM))
         elif variant == "staged":
             _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_STAGED))
+        elif variant == "roles":
+            _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_ROLES))
         elif variant.startswith("quad"):  # quad | quad-<waves>
             _lib.check(self._lib.af_engine_set_kernel(self._h, _lib.KERNEL_QUAD))
             if "-" in variant:

@@ -76,7 +76,8 @@ typedef struct af_block_stats {
 enum { AF_LAYOUT_STREAM_MAJOR = 0 /* [stream][time] */, AF_LAYOUT_TIME_MAJOR = 1 /* [time][stream] */ };
 
 /* kernel variants (all produce the same samples) */
-enum { AF_KERNEL_AUTO = 0, AF_KERNEL_LANE_PER_STREAM = 1, AF_KERNEL_PHASED = 2, AF_KERNEL_QUAD = 3, AF_KERNEL_STAGED = 4 };
+enum { AF_KERNEL_AUTO = 0, AF_KERNEL_LANE_PER_STREAM = 1, AF_KERNEL_PHASED = 2, AF_KERNEL_QUAD = 3, AF_KERNEL_STAGED = 4,
+       AF_KERNEL_ROLES = 5 /* wave roles inside one workgroup per 64 streams, LDS hand-over (csrc/af_roles.hip) */ };
 
 int af_version(void);
 const char *af_last_error(void);
