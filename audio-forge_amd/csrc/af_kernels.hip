@@ -113,7 +113,7 @@ __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompStat
                                              double makeup_lin) {
   const double x = (double)input;
   double d = x;
-  double weight_db = 0.0;
+  double weight_db = kDetectorUnitWeight;  // (dB in the literal build, a linear factor otherwise: af_dsp.h, detector_db)
   if (p.sidechain_highpass_enabled) {
     // process_sidechain_sample, compressor.rs:407-417
     d = p.sidechain_highpass_coeff * (s.sc_prev_out + x - s.sc_prev_in);
@@ -136,7 +136,7 @@ __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompStat
     const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
     const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
     const double w = dclamp(plosive_penalty * presence_weight, 0.35, 1.15);
-    weight_db = lin2db(w, 1e-10);
+    weight_db = detector_weight(w);
   } else {
     s.plosive = 0.0;
   }
@@ -146,11 +146,10 @@ __device__ __forceinline__ float comp_sample(const CompressorParams &p, CompStat
 
   const double sq = d * d;
   s.rms_env_sq = p.rms_coeff * s.rms_env_sq + (1.0 - p.rms_coeff) * sq;
-  const double rms_db = lin2db(sqrt(s.rms_env_sq), 1e-10);
+  const double rms_db = detector_rms_level(s.rms_env_sq);
 
   // blended_detector_db, compressor.rs:681-686
-  const double blended = 0.6 * db2lin(s.peak_env_db) + 0.4 * db2lin(rms_db);
-  const double detector_db = lin2db(blended, 1e-10) + weight_db;
+  const double detector_db = af::detector_db(s.peak_env_db, rms_db, weight_db);
 
   // update_adaptive_release_time_meter + release smoothing, compressor.rs:452-466,752-761.
   // release_coeff = tc(current_release_ms) is only consumed by the non-adaptive branch, where

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_quad_kernel(LaunchAr
       }
       token_pass(turn, kTokCompA, q);
       // ---- feed-forward, own sample: detector weight, instantaneous peak and RMS levels in dB
-      double weight_own = 0.0, plosive_own = 0.0;
+      double weight_own = kDetectorUnitWeight, plosive_own = 0.0;
       if (cp.sidechain_highpass_enabled) {  // update_sidechain_band_metrics, compressor.rs:438-449
         const double low_rms = sqrt(pick(low_e, kq));
         const double voiced_rms = fmax(sqrt(pick(voiced_e, kq)), 1e-8);
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_quad_kernel(LaunchAr
         const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
         const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
         const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
-        weight_own = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
+        weight_own = detector_weight(dclamp(plosive_penalty * presence_weight, 0.35, 1.15));
       }
       const double inst_peak_own = lin2db(fabs(pick(d, kq)), 1e-10);
-      const double rms_db_own = lin2db(sqrt(pick(rms_e, kq)), 1e-10);
+      const double rms_db_own = detector_rms_level(pick(rms_e, kq));
       double inst_peak_db[kChunk], plosive_k[kChunk];
       gather(inst_peak_own, inst_peak_db);
       gather(plosive_own, plosive_k);
@@ -425,8 +425,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_quad_kernel(LaunchAr
       // ---- feed-forward, own sample: blended detector level -> static gain-reduction target
       double target[kChunk];
       {
-        const double blended = 0.6 * db2lin(pick(peak_db, kq)) + 0.4 * db2lin(rms_db_own);
-        gather(comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_own), target);
+        gather(comp_gain_reduction(cp, detector_db(pick(peak_db, kq), rms_db_own, weight_own)), target);
       }
       // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
       double gr_k[kChunk];

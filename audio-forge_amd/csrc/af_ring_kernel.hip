@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) {
-            weight_db[k] = 0.0;
+            weight_db[k] = kDetectorUnitWeight;  // (weight_db / rms_db: dB in the literal build, linear otherwise -- af_dsp.h, detector_db)
             if (cp.sidechain_highpass_enabled) {  // update_sidechain_band_metrics, compressor.rs:438-449
               const double low_rms = sqrt(low_e[k]);
               const double voiced_rms = fmax(sqrt(voiced_e[k]), 1e-8);
@@ -497,10 +497,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
               const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
               const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
               const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
-              weight_db[k] = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
+              weight_db[k] = detector_weight(dclamp(plosive_penalty * presence_weight, 0.35, 1.15));
             }
             inst_peak_db[k] = lin2db(fabs(d[k]), 1e-10);
-            rms_db[k] = lin2db(sqrt(rms_e[k]), 1e-10);
+            rms_db[k] = detector_rms_level(rms_e[k]);
           }
         // ---- token C: log-domain peak envelope (compressor.rs:735-742)
         double peak_db[kChunk];
@@ -522,8 +522,7 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) {
-            const double blended = 0.6 * db2lin(peak_db[k]) + 0.4 * db2lin(rms_db[k]);
-            target[k] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + weight_db[k]);
+            target[k] = comp_gain_reduction(cp, detector_db(peak_db[k], rms_db[k], weight_db[k]));
           }
         // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
         double gr_k[kChunk];

@@ -571,10 +571,9 @@ extern "C" __global__ __launch_bounds__(64 * kFftWaves, 3) void supp_spectrum_ke
 // ============================================================================== analysis, part 2
 // One wave per stream, frames in order: pitch (the octave-error removal looks at the previous frame) and the
 // cepstral history.  Everything it touches is small, so sixteen of these waves share a CU.
-struct PitchLds {
+struct PitchLds {  // (6.2 KB: 4096 one-wave workgroups fit the chip in ONE round -- 25 per CU by LDS, 21.3 needed on 192 CUs; with the
+                   // search's arrays still in here (round 2: 9.9 KB, 16 per CU) the kernel took two)
   float ds[kPitchBuf / 2];
-  float xc[304];
-  float numa[304], da[304];
   float ylk[(kPitchMax >> 1) + 4];
   float ceps[kCepsMem][kRnnBands];
   float Ex[kRnnBands], Ly[kRnnBands];
@@ -810,9 +809,248 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
   }
 }
 
+// ---- pitch, part 1, round 3: FOUR frames of one stream per workgroup (a wave each).  Consecutive frames' 1728-sample windows
+// overlap by 1248 samples, so the workgroup fetches the span once -- coalesced 16-byte loads, all in flight together --
+// into LDS and every wave decimates its frame from there (the one-wave form read 6.9 KB per frame through 42 scalar loads per
+// lane, a few at a time: 28 GB per bench step, and most of a wave's life spent waiting for them).  After the decimation the
+// span's LDS becomes the waves' scan arrays (one workgroup barrier); from there on a wave only ever synchronises with itself.
+// Arithmetic and evaluation orders are the one-wave kernel's: the whitened buffers and pitch indices agree bit for bit.
+template <int MP>
+__device__ __forceinline__ void best_pitch_scan_wave(const float *numa, const float *da, float *syy, float Syy, int lane, int &bp0, int &bp1) {
+#pragma unroll 8
+  for (int i = 0; i < MP; ++i) {
+    syy[i] = Syy;  // same address, same value from every lane
+    Syy = fmaxf(1.0f, Syy + da[i]);
+  }
+  wave_lds_fence();
+  float bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+  bp0 = 0;
+  bp1 = 1;
+#pragma unroll
+  for (int base = 0; base < MP; base += 64) {
+    const int i = base + lane;
+    const float num = i < MP ? numa[i] : -1.0f;
+    const float sy = i < MP ? syy[i] : 1.0f;
+    unsigned long long todo = ~0ull;
+    for (;;) {
+      const bool pass = num >= 0.0f && num * bd1 > bn1 * sy;
+      const unsigned long long m = __ballot(pass) & todo;
+      if (m == 0) break;
+      const int k = __ffsll((long long)m) - 1;
+      const float nk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(num), k));
+      const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), k));
+      if (nk * bd0 > bn0 * sk) {
+        bn1 = bn0; bd1 = bd0; bp1 = bp0;
+        bn0 = nk; bd0 = sk; bp0 = base + k;
+      } else {
+        bn1 = nk; bd1 = sk; bp1 = base + k;
+      }
+      todo = k == 63 ? 0ull : ~0ull << (k + 1);
+    }
+  }
+}
+
+constexpr int kPsFrames = 4;                                   // frames (waves) per workgroup
+constexpr int kPsRaw = kPitchBuf + (kPsFrames - 1) * kRnnFrame;  // samples of the shared span: 3168
+struct PsScan {  // a wave's scan arrays: the coarse stage's (d4, numa, da, syy over 147 lags), then the fine stage's (294 lags)
+  union {
+    struct { float d4[kPitchBuf / 4]; float numa[152], da[152], syy[152]; } c;
+    struct { float xc[304], numa[304], da[304], syy[304]; } f;
+  };
+};
+struct alignas(16) PitchSearch4Lds {
+  float ds[kPsFrames][kPitchBuf / 2];
+  union {
+    float raw[kPsRaw];
+    PsScan scan[kPsFrames];
+  };
+};
+extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch4_kernel(SuppArgs a, SuppTables tb) {
+  __shared__ PitchSearch4Lds L;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int groups = (a.n_frames + kPsFrames - 1) / kPsFrames;
+  const int s = (int)(blockIdx.x / groups), f0 = (int)(blockIdx.x % groups) * kPsFrames;
+  const int f = f0 + wave;
+  const bool live = f < a.n_frames;
+  const int64_t n = (int64_t)a.n_frames * kRnnFrame;
+  const float *xh = a.xh + (int64_t)s * (kPitchBuf + n);
+  {
+    // the span: pitch_buf of frame f0 + k starts 480 k samples into it
+    const int frames_here = (a.n_frames - f0) < kPsFrames ? (a.n_frames - f0) : kPsFrames;
+    const int span = kPitchBuf + (frames_here - 1) * kRnnFrame;  // a multiple of 4
+    const float4 *src = reinterpret_cast<const float4 *>(xh + (int64_t)(f0 + 1) * kRnnFrame);
+    float4 *dst = reinterpret_cast<float4 *>(L.raw);
+    for (int i = tid; i < span / 4; i += 64 * kPsFrames) dst[i] = src[i];
+  }
+  __syncthreads();
+  float *ds = L.ds[wave];
+  if (live) {
+    const float *pb = L.raw + wave * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
+    // ---------------- pitch_downsample (pitch.c): 2x decimation
+    for (int i = lane; i < kPitchBuf / 2; i += 64)
+      ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0]) : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
+  }
+  __syncthreads();  // every wave has left the span: its LDS now holds the scan arrays
+  if (!live) return;
+  PsScan &S = L.scan[wave];
+  const int64_t cell = (int64_t)f * a.n_streams + s;
+  SuppFrameRec *rec = a.rec + cell;
+  // ---------------- LPC-4 whitening
+  float n0, n1, n2, n3, n4;
+  {
+    float ac[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ac[k] = wave_dot64(ds + k, ds, kPitchBuf / 2 - k, lane);
+    ac[0] *= 1.0001f;
+    for (int i = 1; i <= 4; ++i) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
+    float lpc[4] = {0, 0, 0, 0};
+    float error = ac[0];
+    if (ac[0] != 0) {
+      for (int i = 0; i < 4; ++i) {
+        float rr = 0;
+        for (int j = 0; j < i; ++j) rr += lpc[j] * ac[i - j];
+        rr += ac[i + 1];
+        const float r = -rr / error;
+        lpc[i] = r;
+        for (int j = 0; j < (i + 1) >> 1; ++j) {
+          const float t1 = lpc[j], t2 = lpc[i - 1 - j];
+          lpc[j] = t1 + r * t2;
+          lpc[i - 1 - j] = t2 + r * t1;
+        }
+        error = error - r * r * error;
+        if (error < .001f * ac[0]) break;
+      }
+    }
+    float tmp = 1.0f;
+    for (int i = 0; i < 4; ++i) {
+      tmp = .9f * tmp;
+      lpc[i] = lpc[i] * tmp;
+    }
+    const float c1 = .8f;
+    n0 = lpc[0] + .8f;
+    n1 = lpc[1] + c1 * lpc[0];
+    n2 = lpc[2] + c1 * lpc[1];
+    n3 = lpc[3] + c1 * lpc[2];
+    n4 = c1 * lpc[3];
+  }
+  {
+    // celt_fir5 with zero initial memory: y[i] = x[i] + n0 x[i-1] + ... + n4 x[i-5], in that order
+    float yv[14];
+    int cnt = 0;
+    for (int i = lane; i < kPitchBuf / 2; i += 64, ++cnt) {
+      float sum = ds[i];
+      sum += n0 * (i >= 1 ? ds[i - 1] : 0.0f);
+      sum += n1 * (i >= 2 ? ds[i - 2] : 0.0f);
+      sum += n2 * (i >= 3 ? ds[i - 3] : 0.0f);
+      sum += n3 * (i >= 4 ? ds[i - 4] : 0.0f);
+      sum += n4 * (i >= 5 ? ds[i - 5] : 0.0f);
+      yv[cnt] = sum;
+    }
+    wave_lds_fence();
+    cnt = 0;
+    for (int i = lane; i < kPitchBuf / 2; i += 64, ++cnt) ds[i] = yv[cnt];
+  }
+  wave_lds_fence();
+  // the whitened buffer goes out now (the pitch tracker reads it), while the search runs
+  {
+    float *dsg = a.ds + cell * (kPitchBuf / 2);
+    for (int i = lane; i < kPitchBuf / 2; i += 64) dsg[i] = ds[i];
+  }
+  // ---------------- pitch_search(x_lp = ds + 384, y = ds, len 960, max_pitch 588)
+  const int max_pitch = kPitchMax - 3 * kPitchMin;  // 588
+  const float *x_lp = ds + (kPitchMax >> 1);
+  int best0, best1;
+  {
+    // coarse: 4x decimated, 147 lags x 240 products on the matrix cores (see the one-wave kernel above)
+    constexpr int len = kRnnWindow >> 2, mp = (kPitchMax - 3 * kPitchMin) >> 2;
+    for (int i = lane; i < kPitchBuf / 4; i += 64) S.c.d4[i] = ds[2 * i];
+    wave_lds_fence();
+    {
+      typedef float v4f_ps __attribute__((ext_vector_type(4)));
+      v4f_ps acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int col = lane & 15, kq = lane >> 4;
+      const float *ap = S.c.d4 + kq + col;          // y[4 s + k + i]
+      const float *x4 = S.c.d4 + (kPitchMax >> 2);  // x[j] = x_lp[2 j]
+      int xi = kq - 16 * col;                       // 4 s + k - 16 c at s = 0
+#pragma unroll 4
+      for (int st = 0; st < 96; ++st) {
+        const float av = ap[4 * st];
+        const bool in = (unsigned)xi < (unsigned)len;
+        const float bv = in ? x4[in ? xi : 0] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        xi += 4;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lag = 16 * col + kq * 4 + r;
+        if (lag < mp) {
+          const float sum = acc[r];
+          const float x16 = sum * 1e-12f;
+          S.c.numa[lag] = sum > 0 ? x16 * x16 : -1.0f;
+          const float ya = S.c.d4[lag + len], yb = S.c.d4[lag];
+          S.c.da[lag] = ya * ya - yb * yb;
+        }
+      }
+    }
+    float Syy0;
+    {
+      float acc = 0.0f;
+      for (int i = lane; i < len; i += 64) acc = acc + S.c.d4[i] * S.c.d4[i];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+      Syy0 = 1.0f + acc;
+    }
+    wave_lds_fence();
+    static_assert(mp == 147, "coarse lag count");
+    best_pitch_scan_wave<mp>(S.c.numa, S.c.da, S.c.syy, Syy0, lane, best0, best1);
+  }
+  wave_lds_fence();  // the coarse arrays are dead: the fine stage's take their place
+  {
+    // fine: 2x decimated, only within +-2 of the two coarse candidates (at most ten lags)
+    constexpr int len = kRnnWindow >> 1, mp = (kPitchMax - 3 * kPitchMin) >> 1;
+    for (int i = lane; i < mp; i += 64) {
+      S.f.xc[i] = 0.0f;
+      S.f.numa[i] = -1.0f;
+      const float ya = ds[i + len], yb = ds[i];
+      S.f.da[i] = ya * ya - yb * yb;
+    }
+    wave_lds_fence();
+    for (int c = 0; c < 2; ++c) {
+      const int centre = 2 * (c == 0 ? best0 : best1);
+      for (int i = centre - 2; i <= centre + 2; ++i) {
+        if (i < 0 || i >= mp) continue;
+        if (c == 1) {
+          const int d0 = i - 2 * best0;
+          if (d0 <= 2 && d0 >= -2) continue;  // already done for the first candidate
+        }
+        const float v = fmaxf(-1.0f, wave_dot64(x_lp, ds + i, len, lane));
+        if (lane == 0) {
+          S.f.xc[i] = v;
+          const float x16 = v * 1e-12f;
+          S.f.numa[i] = v > 0 ? x16 * x16 : -1.0f;
+        }
+      }
+    }
+    const float Syy0 = 1.0f + wave_dot64(ds, ds, len, lane);
+    wave_lds_fence();
+    best_pitch_scan_wave<mp>(S.f.numa, S.f.da, S.f.syy, Syy0, lane, best0, best1);
+  }
+  int pitch_index;
+  {
+    int offset = 0;
+    if (best0 > 0 && best0 < (max_pitch >> 1) - 1) {
+      const float pa = S.f.xc[best0 - 1], pbv = S.f.xc[best0], pc = S.f.xc[best0 + 1];
+      if ((pc - pa) > .7f * (pbv - pa)) offset = 1;
+      else if ((pa - pc) > .7f * (pbv - pc)) offset = -1;
+    }
+    pitch_index = kPitchMax - (2 * best0 - offset);
+  }
+  if (lane == 0) rec->pitch_index = pitch_index;
+}
+
 // ---- pitch, part 2: what looks at the previous frame (wave per stream, frames in order): octave-error removal
 // (remove_doubling compares with the last period and gain), the cepstral ring and the features built on it.
-extern "C" __global__ __launch_bounds__(64, 4) void supp_pitch_kernel(SuppArgs a, SuppTables tb) {
+extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a, SuppTables tb) {
   __shared__ PitchLds L;
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
@@ -1794,7 +2032,16 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
     hipError_t err = hipStreamWaitEvent(stream, before_pitch, 0);
     if (err != hipSuccess) return err;
   }
-  hipLaunchKernelGGL(supp_pitchsearch_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  static const bool search4 = [] {  // AF_PITCHSEARCH4=0: the round-2 form, one frame (wave) per workgroup (same-box A/B)
+    const char *env = std::getenv("AF_PITCHSEARCH4");
+    return !env || std::atoi(env) != 0;
+  }();
+  if (search4) {
+    const unsigned groups = (unsigned)((a.n_frames + kPsFrames - 1) / kPsFrames);
+    hipLaunchKernelGGL(supp_pitchsearch4_kernel, dim3((unsigned)a.n_streams * groups), dim3(64 * kPsFrames), 0, stream, a, tb);
+  } else {
+    hipLaunchKernelGGL(supp_pitchsearch_kernel, dim3((unsigned)((int64_t)a.n_streams * a.n_frames)), dim3(64), 0, stream, a, tb);
+  }
   hipLaunchKernelGGL(supp_pitch_kernel, dim3(a.n_streams), dim3(64), 0, stream, a, tb);
   return hipGetLastError();
 }

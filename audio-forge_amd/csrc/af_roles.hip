@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * kCompWaves) void chain_comp_roles_kernel(Launc
         const int64_t ti = it - 2;
         if (ti >= 0 && ti < ntiles && t < tile_len(ti)) {
           const int b = (int)(ti & 1), b4 = (int)(ti & 3);
-          double weight_db = 0.0, plosive_last = 0.0;
+          double weight_db = kDetectorUnitWeight, plosive_last = 0.0;  // (WDB / RMSDB: dB in the literal build, linear otherwise)
           if (kSc) {
             const double low_rms = sqrt(L.LOW[b][t][lane]);
             const double voiced_rms = fmax(sqrt(L.VOI[b][t][lane]), 1e-8);
@@ -257,11 +257,11 @@ __global__ __launch_bounds__(64 * kCompWaves) void chain_comp_roles_kernel(Launc
             const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
             const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
             const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
-            weight_db = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
+            weight_db = detector_weight(dclamp(plosive_penalty * presence_weight, 0.35, 1.15));
           }
           L.WDB[b4][t][lane] = weight_db;
           L.IPK[b][t][lane] = lin2db(fabs(L.D[b][t][lane]), 1e-10);
-          L.RMSDB[b4][t][lane] = lin2db(sqrt(L.RMS[b][t][lane]), 1e-10);
+          L.RMSDB[b4][t][lane] = detector_rms_level(L.RMS[b][t][lane]);
           if (ti * kRT + t == n - 1) L.PLOS[lane] = plosive_last;
         }
       }
@@ -270,8 +270,7 @@ __global__ __launch_bounds__(64 * kCompWaves) void chain_comp_roles_kernel(Launc
         const int64_t ti = it - 4;
         if (ti >= 0 && ti < ntiles && t < tile_len(ti)) {
           const int b = (int)(ti & 1), b4 = (int)(ti & 3);
-          const double blended = 0.6 * db2lin(L.PEAK[b][t][lane]) + 0.4 * db2lin(L.RMSDB[b4][t][lane]);
-          L.TARGET[b][t][lane] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + L.WDB[b4][t][lane]);
+          L.TARGET[b][t][lane] = comp_gain_reduction(cp, detector_db(L.PEAK[b][t][lane], L.RMSDB[b4][t][lane], L.WDB[b4][t][lane]));
         }
       }
       {

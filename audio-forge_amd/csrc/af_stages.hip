@@ -411,7 +411,7 @@ __device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const int64_t row = gb + e.idx;
-    double weight_db = 0.0, plosive_last = 0.0;
+    double weight_db = kDetectorUnitWeight, plosive_last = 0.0;  // (the w_db / rms_db rings: dB in the literal build, linear otherwise)
     if (cp.sidechain_highpass_enabled) {
       const double low_rms = sqrt(i_low[k]);
       const double voiced_rms = fmax(sqrt(i_voiced[k]), 1e-8);
@@ -422,11 +422,11 @@ __device__ __forceinline__ void stage_f1_body(const StageArgs &a, int bx, int by
       const double plosive_penalty = 1.0 - plosive_amount * (1.0 - 0.35);
       const double presence_ratio = dclamp(presence_rms / voiced_rms, 0.0, 4.0);
       const double presence_weight = 1.0 + 0.18 * dclamp(presence_ratio - 0.75, 0.0, 1.0);
-      weight_db = lin2db(dclamp(plosive_penalty * presence_weight, 0.35, 1.15), 1e-10);
+      weight_db = detector_weight(dclamp(plosive_penalty * presence_weight, 0.35, 1.15));
     }
     a.r.w_db[row] = weight_db;
     a.r.ipk_db[row] = lin2db(fabs(i_d[k]), 1e-10);
-    a.r.rms_db[row] = lin2db(sqrt(i_rms[k]), 1e-10);
+    a.r.rms_db[row] = detector_rms_level(i_rms[k]);
     if (e.abs == a.n0 + a.n - 1 && s < a.n_streams) a.st64[(int64_t)kCompPlosive * NS + s] = plosive_last;  // diagnostic state only
   }
 }
@@ -490,8 +490,7 @@ __device__ __forceinline__ void stage_f2_body(const StageArgs &a, int bx, int by
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const int64_t row = gb + e.idx;
-    const double blended = 0.6 * db2lin(pk[k]) + 0.4 * db2lin(rm[k]);
-    a.r.target[row] = comp_gain_reduction(cp, lin2db(blended, 1e-10) + wd[k]);
+    a.r.target[row] = comp_gain_reduction(cp, detector_db(pk[k], rm[k], wd[k]));
   }
 }
 
