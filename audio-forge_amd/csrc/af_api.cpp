@@ -56,6 +56,7 @@ constexpr size_t kMaxLdsBytes = 160 * 1024;
 // streams 202 (the hand-over rings cost 0.3 KB per sample step per stream: the HBM roof); beyond that the token ring wins
 // (a launch of it lasts ~202 ms up to 16 384 streams).  Behind the suppressor, whose kernels use the same HBM, up to 2048.
 constexpr int kStagedAutoMaxStreams = 3072, kStagedAutoMaxStreamsBehindSuppressor = 2048;
+constexpr int kEqParamSlots = 16;  // parameter blocks the EQ / de-esser stages read: one per window in flight (af_engine::d_params_eq)
 
 static_assert(sizeof(af_block_stats) == sizeof(af::BlockStats), "stats row layout");
 static_assert(sizeof(af_block_stats) == 72, "stats row size");
@@ -103,6 +104,7 @@ struct af_engine {
   af::ChainParams *d_params_eq = nullptr;     // [1 + extra_presets.size()]: what the systolic EQ kernel reads (af_eq_systolic.hip)
   std::vector<af::ChainParams> uploaded_eq;
   int eq_params_presets = 0;
+  uint64_t eq_slot_cursor = 0;               // stage pipeline with the de-esser: the next window's parameter slot
   std::vector<af::ChainParams> uploaded_multi;
   int n_streams;
   int device;
@@ -135,7 +137,7 @@ struct af_engine {
   // Parameter uploads go through engine-owned pinned staging slots (stage_upload): the host never waits for a stream, and
   // a slot is only reused once the copy that read it has run.
   struct ParamStager {
-    static constexpr int kSlots = 8;
+    static constexpr int kSlots = 32;      // (the stage pipeline with the de-esser uploads one block per window: the host may run this many windows ahead)
     af::ChainParams *pinned = nullptr;     // [kSlots][blocks_per_slot]
     size_t blocks_per_slot = 0;
     hipEvent_t done[kSlots] = {};
@@ -196,6 +198,7 @@ struct af_engine {
     double *d_bp = nullptr;                // auto-makeup: block powers, written seven launch steps before they are read
     int64_t call_stride = 0;               // stream stride of the call being scheduled
     const af::ChainParams *d_chain = nullptr;  // the parameter block(s) the stages read (an array with several presets)
+    bool with_deesser = false;             // the rings include the de-esser stages'
     int32_t w_min = 1;                     // smallest lookahead + 1 over the presets
     uint32_t strip = 0;                    // chain flags another kernel has taken over (the suppressor's pre-pass)
   } pipe;
@@ -229,7 +232,7 @@ int stage_upload(af_engine *e, af::ChainParams *dst, const af::ChainParams *src,
   const int slot = st.next;
   st.next = (st.next + 1) % af_engine::ParamStager::kSlots;
   if (!st.done[slot]) AF_HIP(hipEventCreateWithFlags(&st.done[slot], hipEventDisableTiming));
-  if (st.used[slot]) AF_HIP(hipEventSynchronize(st.done[slot]));  // eight uploads ago: long done
+  if (st.used[slot]) AF_HIP(hipEventSynchronize(st.done[slot]));  // kSlots uploads ago: normally long done
   af::ChainParams *host = st.pinned + (size_t)slot * st.blocks_per_slot;
   std::memcpy(host, src, sizeof(af::ChainParams) * count);
   AF_HIP(hipMemcpyAsync(dst, host, sizeof(af::ChainParams) * count, hipMemcpyHostToDevice, stream));
@@ -828,7 +831,9 @@ int engine_event(af_engine *e, hipEvent_t *out_ev) {
 // ---------------------------------------------------------------------------------------------------------------------
 // The stage-pipeline form of the chain (af_stages.hip).  Which configurations it serves:
 bool stage_pipe_serves_one(const af::ChainParams &run) {
-  if (run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
+  if (run.flags & (af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) return false;
+  // the de-esser in its default place (ahead of the EQ) runs as stages of its own; EQ-before-de-esser stays on kernel 2
+  if ((run.flags & af::kFlagDeesser) && (run.flags & af::kFlagEqBeforeDeesser)) return false;
   if ((run.flags & af::kFlagEq) && run.n_eq_sections > 16) return false;
   if ((run.flags & af::kFlagLimiter) && run.lim.lookahead_samples > af::kMaxLookahead) return false;
   return true;
@@ -874,10 +879,11 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
       sp.mk_rows = rows;
     }
   }
-  if (sp.rings.xe && tw_max <= sp.tw_max) return AF_OK;
+  if (sp.rings.xe && tw_max <= sp.tw_max && sp.with_deesser == ((e->host_params.flags & af::kFlagDeesser) != 0)) return AF_OK;
   if (sp.rings.xe) {  // grow: only between calls of a fresh engine (the rings hold the histories)
-    if (sp.windows > 0) return fail(AF_ERR_UNSUPPORTED, "a call of %lld samples per window after smaller ones: the stage pipeline's rings were sized for %lld",
-                                    (long long)tw_max, (long long)sp.tw_max);
+    if (sp.windows > 0 && tw_max > sp.tw_max)
+      return fail(AF_ERR_UNSUPPORTED, "a call of %lld samples per window after smaller ones: the stage pipeline's rings were sized for %lld",
+                  (long long)tw_max, (long long)sp.tw_max);
     AF_HIP(hipDeviceSynchronize());
     for (void *p : sp.allocs) (void)hipFree(p);
     sp.allocs.clear();
@@ -887,7 +893,10 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   const int64_t hist = 2 * (af::kMaxLookahead + 1) + 64;
   // a ring holds the windows between its producer and its last consumer, one more, and the history: the stages advance in lock
   // step, an f64 ring's reader two windows behind its writer at most, the EQ output's last reader seven
-  const size_t r64 = pow2_at_least(4 * tw_max + hist), r32 = pow2_at_least(10 * tw_max + hist);
+  const bool deesser = (e->host_params.flags & af::kFlagDeesser) != 0;
+  // (with the de-esser: a band's coefficients wait three launch steps for the third dynamic EQ of the cascade, and the chain
+  // input nine for nothing -- the EQ now reads the de-esser's output ring)
+  const size_t r64 = pow2_at_least((deesser ? 6 : 4) * tw_max + hist), r32 = pow2_at_least(10 * tw_max + hist);
   sp.rings.rows_f64 = (int32_t)r64;
   sp.rings.rows_f32 = (int32_t)r32;
   auto ring32 = [&](float **p) -> hipError_t {
@@ -906,6 +915,16 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
   for (float **p : {&r.xi, &r.xe, &r.xc, &r.sfx, &r.xl, &r.itp, &r.tgt, &r.gt, &r.od}) AF_HIP(ring32(p));
   for (double **p : {&r.d, &r.pr, &r.low_e, &r.voiced_e, &r.pres_e, &r.rms_e, &r.ipk_db, &r.rms_db, &r.w_db, &r.peak_db, &r.target, &r.gr, &r.glin, &r.fast_r, &r.slow_r, &r.tgt_ms, &r.tg, &r.g})
     AF_HIP(ring64(p));
+  if (deesser) {
+    for (int b = 0; b < 3; ++b) {
+      for (double **p : {&r.de_env[b], &r.de_ct[b], &r.de_ratio[b], &r.de_aux[b], &r.de_tr[b], &r.de_gdb[b]}) AF_HIP(ring64(p));
+      for (int j = 0; j < 5; ++j) AF_HIP(ring64(&r.de_c[b][j]));
+      AF_HIP(ring32(&r.de_y[b]));
+    }
+    AF_HIP(ring64(&r.de_bb));
+    AF_HIP(ring32(&r.de_upd));
+  }
+  sp.with_deesser = deesser;
   sp.tw_max = tw_max;
   if (!sp.stream) {  // (a queue of its own: a CU-masked stream with every CU enabled; plain streams share a few hardware queues)
     hipDeviceProp_t prop;
@@ -928,6 +947,15 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
   for (float *p : {r.xi, r.xe, r.xc, r.sfx, r.xl, r.itp, r.tgt, r.gt, r.od}) AF_HIP(hipMemset(p, 0, sizeof(float) * r.rows_f32 * 64 * groups));
   for (double *p : {r.d, r.pr, r.low_e, r.voiced_e, r.pres_e, r.rms_e, r.ipk_db, r.rms_db, r.w_db, r.peak_db, r.target, r.gr, r.glin, r.fast_r, r.slow_r, r.tgt_ms, r.tg, r.g})
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+  if (sp.with_deesser) {
+    for (int b = 0; b < 3; ++b) {
+      for (double *p : {r.de_env[b], r.de_ct[b], r.de_ratio[b], r.de_aux[b], r.de_tr[b], r.de_gdb[b]}) AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+      for (int j = 0; j < 5; ++j) AF_HIP(hipMemset(r.de_c[b][j], 0, sizeof(double) * r.rows_f64 * 64 * groups));
+      AF_HIP(hipMemset(r.de_y[b], 0, sizeof(float) * r.rows_f32 * 64 * groups));
+    }
+    AF_HIP(hipMemset(r.de_bb, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+    AF_HIP(hipMemset(r.de_upd, 0, sizeof(float) * r.rows_f32 * 64 * groups));
+  }
   sp.windows = 0;
   return AF_OK;
 }
@@ -971,8 +999,25 @@ StagePlan stage_plan(const af::ChainParams &run) {
   StagePlan p;
   const bool comp = (run.flags & af::kFlagCompressor) != 0, lim = (run.flags & af::kFlagLimiter) != 0;
   auto add = [&](int k, int sk) { p.stage[p.n] = k; p.skew[p.n] = sk; ++p.n; p.depth = std::max(p.depth, sk); return sk; };
-  int at = add(af::kStEq, 0);
-  add(af::kStIn, 1);
+  int at = 0;
+  if (run.flags & af::kFlagDeesser) {
+    // the de-esser ahead of the EQ (deesser.rs:405-547): transposing loader | three detectors | levels and confidence targets |
+    // three confidence / baseline recurrences | scaling, reduction smoothing, gain hold | coefficients | three cascaded dynamic EQs
+    add(af::kStDe0, 0);
+    for (int k : {af::kStDe1a, af::kStDe1b, af::kStDe1c}) add(k, 1);
+    add(af::kStDe2, 2);
+    for (int k : {af::kStDe3a, af::kStDe3b, af::kStDe3c}) add(k, 3);
+    add(af::kStDe4, 4);
+    add(af::kStDe5, 5);
+    add(af::kStDe6a, 6);
+    add(af::kStDe6b, 7);
+    add(af::kStDe6c, 8);
+    at = add(af::kStEq, 9);
+  } else {
+    at = add(af::kStEq, 0);
+  }
+  const int eq_at = at;
+  add(af::kStIn, 1);  // (the xi ring: written by the EQ stage, or by the de-esser's loader, one step earlier)
   if (comp) {
     for (int k : {af::kStCompA, af::kStCompA2, af::kStF1, af::kStCompC, af::kStF2, af::kStCompE}) at = add(k, at + 1);
     if (run.comp.adaptive_release) {
@@ -980,7 +1025,7 @@ StagePlan stage_plan(const af::ChainParams &run) {
       add(af::kStRel, at + 2);
     }
     if (run.comp.auto_makeup_enabled) {
-      add(af::kStPow, 1);
+      add(af::kStPow, eq_at + 1);
       at = add(af::kStF3a, at + 1);
       at = add(af::kStMakeup, at + 1);
     } else {
@@ -1012,14 +1057,15 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
   d.adaptive = run.comp.adaptive_release;
   d.auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
   d.base.stream_stride = sp.call_stride;
-  // two dispatches per step: the one-wave workgroups (serial stages and F4), then the wide stages
-  for (int pass = 0; pass < 2; ++pass) {
+  d.deesser = (run.flags & af::kFlagDeesser) ? 1 : 0;
+  // two dispatches per step: the one-wave workgroups (serial stages and F4), then the wide stages; with the de-esser a third
+  // for its serial stages
+  for (int pass = 0; pass < (d.deesser ? 3 : 2); ++pass) {
     unsigned blocks = 0;
     d.n_roles = 0;
     for (int i = 0; i < plan.n; ++i) {
       const int k = plan.stage[i];
-      const bool wide = k == af::kStF1 || k == af::kStF2 || k == af::kStFR || k == af::kStF3 || k == af::kStF3a || k == af::kStF5 || k == af::kStF6;
-      if (wide != (pass == 1)) continue;
+      if (af::stage_dispatch_kind(k) != pass) continue;
       const int64_t wi = j - plan.skew[i];
       if (wi < 0 || wi >= (int64_t)wins.size()) continue;
       af::DiagRole &role = d.roles[d.n_roles++];
@@ -1037,7 +1083,7 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
       AF_HIP(hipEventCreate(&t1));
       AF_HIP(hipEventRecord(t0, stream));
     }
-    AF_HIP(af::launch_stage_diag(d, blocks, pass == 1, stream));
+    AF_HIP(af::launch_stage_diag(d, blocks, pass, stream));
     if (t0) {
       AF_HIP(hipEventRecord(t1, stream));
       e->chain_ms_events.push_back({t0, t1});
@@ -1048,22 +1094,38 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
 }
 
 // the EQ stage's parameter block for the window about to enter the pipeline (stream-ordered behind the previous window's launch)
-int stage_diag_eq_params(af_engine *e, hipStream_t stream, bool *crossfade) {
+int stage_diag_eq_params(af_engine *e, hipStream_t stream, bool *crossfade, int32_t *slot_out) {
   const int n_presets = 1 + (int)e->extra_presets.size();
   std::vector<af::ChainParams> runs((size_t)n_presets);
   *crossfade = false;
+  bool deesser = false;
   for (int p = 0; p < n_presets; ++p) {
     runs[p] = preset_params(e, p);
     runs[p].flags &= ~e->pipe.strip;
     for (int k = 0; k < runs[p].n_eq_sections; ++k) *crossfade |= runs[p].eq[k].xf_remaining > 0;
+    if (runs[p].flags & af::kFlagDeesser) {
+      deesser = true;
+      runs[p].flags &= ~(af::kFlagInputScrub | af::kFlagInputClamp);  // the de-esser's loader stage scrubbed the input already
+    }
   }
+  // With the de-esser every window keeps a parameter block of its own for as long as it is in the pipeline: the de-esser's
+  // stages read their filters' crossfade counters as of the window's first sample up to eight launch steps after it entered.
+  constexpr int kSlots = kEqParamSlots;
   if (!e->d_params_eq || e->eq_params_presets != n_presets) {
     if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
     e->d_params_eq = nullptr;
-    AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets));
+    AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets * kSlots));
     e->eq_params_presets = n_presets;
     e->uploaded_eq.clear();
   }
+  if (deesser) {
+    const int slot = (int)(e->eq_slot_cursor++ % kSlots);
+    if (int rc = stage_upload(e, e->d_params_eq + (size_t)slot * n_presets, runs.data(), runs.size(), stream)) return rc;
+    e->uploaded_eq.clear();
+    *slot_out = slot * n_presets;
+    return AF_OK;
+  }
+  *slot_out = 0;
   if (e->uploaded_eq.size() != runs.size() || std::memcmp(e->uploaded_eq.data(), runs.data(), sizeof(af::ChainParams) * runs.size()) != 0) {
     e->uploaded_eq = runs;
     if (int rc = stage_upload(e, e->d_params_eq, runs.data(), runs.size(), stream)) return rc;
@@ -1434,10 +1496,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       return env ? std::atoi(env) : -1;
     }();
     if (e->kernel == AF_KERNEL_STAGED && !serves)
-      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (de-esser, front end without the "
+      return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (EQ-before-de-esser order, front end without the "
                                       "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
+    // (with the de-esser at any batch: its lane-per-stream form takes 417 ms per 2 s of audio whatever the batch)
+    const bool deesser_staged = (probe.flags & af::kFlagDeesser) != 0;
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 &&
-                                 e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams)) ||
+                                 (deesser_staged || e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams))) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));
     e->pipe.decided = true;
     if (e->pipe.active)
@@ -1533,7 +1597,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       for (int64_t j = 0; j < steps; ++j) {
         if (j < (int64_t)wins.size()) {  // window j enters: its EQ stage reads the section parameters as they stand now
           bool crossfade = false;
-          if (int rc = stage_diag_eq_params(e, stream, &crossfade)) return rc;
+          if (int rc = stage_diag_eq_params(e, stream, &crossfade, &wins[(size_t)j].eq_slot)) return rc;
           wins[(size_t)j].eq_crossfade = crossfade ? 1 : 0;
           advance_crossfades(e, wins[(size_t)j].n);
         }
@@ -1864,7 +1928,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         wd.in = out + seg0 + off;
         wd.out = out + seg0 + off;
         bool crossfade = false;
-        if (int rc2 = stage_diag_eq_params(e, ds, &crossfade)) return rc2;
+        if (int rc2 = stage_diag_eq_params(e, ds, &crossfade, &wd.eq_slot)) return rc2;
         wd.eq_crossfade = crossfade ? 1 : 0;
         diag_wins.push_back(wd);
         if (int rc2 = stage_diag_step(e, run, diag_plan, diag_wins, (int64_t)diag_wins.size() - 1, ds)) return rc2;
@@ -1894,7 +1958,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         if (!e->d_params_eq || e->eq_params_presets != n_presets) {
           if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
           e->d_params_eq = nullptr;
-          AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets));
+          AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * n_presets * kEqParamSlots));  // (sized as the stage pipeline sizes it)
           e->eq_params_presets = n_presets;
           e->uploaded_eq.clear();
         }

@@ -21,6 +21,7 @@ struct EqSystolicArgs {
   int64_t n_samples, stream_stride, n0;
   int32_t n_streams, ring_rows;
   double *block_power;          // [block][stream]: sum of squares of the filtered samples of each control block (kPower), or null
+  const float *ring_src;        // the input comes from this ring of the stage pipeline (the de-esser stages' output) instead of `in`
 };
 
 template <int N>
@@ -87,11 +88,12 @@ __device__ __forceinline__ void eq_systolic_body(const EqSystolicArgs &a, int bl
     return ((na >> 2) & (int64_t)(a.ring_rows / 4 - 1)) * (kLanes * 4) + ring_lane * 4 + (na & 3);
   };
   const float *row_in = a.in + (int64_t)sc * a.stream_stride;
+  const float *ring_src = a.ring_src ? a.ring_src + (int64_t)(sc >> 6) * a.ring_rows * kLanes : nullptr;
   const int64_t n = a.n_samples;
   const int64_t groups = (n + 15) / 16;
   auto fetch = [&](int64_t g) -> float {
     const int64_t t = g * 16 + k;
-    float v = (g < groups && t < n) ? row_in[t] : 0.0f;
+    float v = (g < groups && t < n) ? (ring_src ? ring_src[ring_at(t)] : row_in[t]) : 0.0f;
     if (scrub && !finite_f32(v)) v = 0.0f;  // python_api.rs:515-523 / routing.rs:802-823 (every lane scrubs its own sample)
     if (clamp) v = fclamp(v, -1.0f, 1.0f);
     if (ring_in && valid && g < groups && t < n) ring_in[ring_at(t)] = v;

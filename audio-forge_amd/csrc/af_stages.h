@@ -32,6 +32,14 @@ struct StageRings {
   float *itp, *tgt;                              // 4x true peak of xl and the target gain it asks for
   float *gt;                                     // true-peak limiter gain
   float *od;                                     // chain output (time-major), input of the output-side detector
+  // de-esser stages (allocated only when the de-esser is on)
+  double *de_env[3], *de_bb;                     // band envelopes, broadband envelope
+  double *de_ct[3], *de_ratio[3], *de_aux[3];    // confidence target, band-to-voice ratio (dB), voice-active flag / band level (dB)
+  double *de_tr[3];                              // raw reduction targets (dB)
+  double *de_gdb[3];                             // the dynamic EQs' gains after the 0.001 dB hold
+  float *de_upd;                                 // bit i: band i's coefficients change at this sample
+  double *de_c[3][5];                            // the coefficients they change to
+  float *de_y[3];                                // audio after dynamic EQ 0, 1, 2
   int32_t rows_f32, rows_f64;                    // ring lengths
 };
 
@@ -75,6 +83,14 @@ enum StageId : int {
   kStTp,       // serial: true-peak gain
   kStOut,      // serial: chain output, block output statistics
   kStF6,       // output-side 4x true peak, time-major -> stream-major
+  // the de-esser (deesser.rs:405-547) ahead of the EQ: every recurrence a stage of its own
+  kStDe0,      // stream-major audio -> the xi ring (scrub / clamp)
+  kStDe1a, kStDe1b, kStDe1c,  // serial, one per band: detector high-pass -> low-pass -> envelope (band 0 also the broadband envelope)
+  kStDe2,      // levels in dB, voice reference, narrowness, dominance, confidence targets
+  kStDe3a, kStDe3b, kStDe3c,  // serial, one per band: confidence, baseline, raw reduction target
+  kStDe4,      // serial: target scaling, reduction smoothing, the 0.001 dB hold on the dynamic EQs' gains, block figure
+  kStDe5,      // the peaking coefficients of every changed gain
+  kStDe6a, kStDe6b, kStDe6c,  // serial, cascaded: the three dynamic EQs
   kStCount
 };
 
@@ -104,9 +120,12 @@ struct DiagArgs {
   int32_t n_roles;
   uint32_t flags;              // chain flags the pipeline was planned for
   int32_t sidechain, adaptive, auto_makeup;  // compressor switches (they pick code paths)
+  int32_t deesser;             // the de-esser stages run ahead of the EQ (which then reads their output ring)
 };
-// `wide`: the roles are the wide stages F1, F2, FR, F3, F5, F6 (workgroups of four waves); else all the others (one wave)
-hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream);
+// `kind` (stage_dispatch_kind): 0 = the one-wave roles (serial stages, F4, the EQ), 1 = the wide stages (workgroups of four
+// waves), 2 = the de-esser's serial stages (one wave each, a kernel of their own)
+int stage_dispatch_kind(int stage);
+hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, int kind, hipStream_t stream);
 // blocks a role needs for a window: `gx` (the launch uses gx * gy blocks, gy = groups except for the EQ stage)
 unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, int32_t w_min, unsigned *gy);
 

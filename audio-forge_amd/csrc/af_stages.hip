@@ -27,6 +27,7 @@
 
 #include <type_traits>
 
+#include "af_deesser_math.h"
 #include "af_dsp.h"
 #include "af_eq_systolic_body.h"
 #include "af_stages.h"
@@ -1222,8 +1223,7 @@ __device__ __forceinline__ void stage_out_body(const StageArgs &a, const float *
 // ============================================================================================ feed-forward 6
 // output-side 4x true peak (TruePeakDetector::process_block, true_peak.rs:205-221; block_processor.rs:159) folded into the
 // block maximum, and the chain output back in stream-major order.  Tiles of 64 steps at absolute multiples of 64.
-__device__ __forceinline__ void stage_f6_body(const StageArgs &a, int bx, int by) {
-  __shared__ float tile[kTileRows][kLanes + 1];
+__device__ __forceinline__ void stage_f6_body(const StageArgs &a, float (&tile)[kTileRows][kLanes + 1], int bx, int by) {
   const int g = by;
   const Who w = who(a, g);
   const ChainParams &P = preset(a, g);
@@ -1274,6 +1274,485 @@ __device__ __forceinline__ void stage_f6_body(const StageArgs &a, int bx, int by
 }
 
 
+// ============================================================================================ de-esser stages
+// The three-band dynamic de-esser (deesser.rs:405-547; af_deesser.hip is the lane-per-stream form: one wave per 64 streams
+// walking ~1 200 dependent instructions per sample, 417 ms per 2 s of audio at any batch).  Nothing in it feeds back from the
+// audio it produces: detectors (six biquads + four envelopes) -> levels and confidence targets (pure math) -> confidence /
+// baseline / raw targets (three small recurrences) -> scaling, reduction smoothing and the 0.001 dB hold (one recurrence) ->
+// peaking coefficients (pure math) -> three cascaded dynamic EQs.  So it cuts into stages like the rest of the chain; the
+// stages read the same state rows as the lane kernel and use its expressions (af_deesser_math.h): the same bits.
+using namespace deess;
+
+// stream-major audio -> the xi ring, scrubbed / clamped (python_api.rs:515-523, routing.rs:802-823); tiles of 64 steps
+__device__ __forceinline__ void stage_de0_body(const StageArgs &a, float (&tile)[kTileRows][kLanes + 1], uint32_t flags, int bx, int by) {
+  const int g = by;
+  const Who w = who(a, g);
+  const int wave = threadIdx.x >> 6;
+  const int R32 = a.r.rows_f32;
+  float *xi = a.r.xi + (int64_t)g * R32 * kLanes;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t abs0 = ((n0 >> 6) + bx) * kTileRows;
+  const bool scrub = (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = (flags & kFlagInputClamp) != 0;
+#pragma unroll 4
+  for (int r = wave * 16; r < wave * 16 + 16; ++r) {  // lane = time: a 256-byte run of one stream
+    const int s = g * kLanes + r;
+    const int64_t t = abs0 + w.lane - n0;
+    float v = 0.0f;
+    if (s < a.n_streams && t >= 0 && t < a.n) v = a.in[(int64_t)s * a.stream_stride + t];
+    if (scrub && !finite_f32(v)) v = 0.0f;
+    if (clamp) v = fclamp(v, -1.0f, 1.0f);
+    tile[w.lane][r] = v;
+  }
+  __syncthreads();
+  const int64_t first = abs0 + wave * 16;  // lane = stream: this wave's sixteen steps, a quad at a time
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t qa = first + 4 * k;
+    float *p = xi + qoff(qa >> 2, R32) + w.lane * kQ;
+    if (qa >= n0 && qa + 3 < n_end) {
+      *reinterpret_cast<float4 *>(p) = make_float4(tile[wave * 16 + 4 * k][w.lane], tile[wave * 16 + 4 * k + 1][w.lane],
+                                                   tile[wave * 16 + 4 * k + 2][w.lane], tile[wave * 16 + 4 * k + 3][w.lane]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (qa + j >= n0 && qa + j < n_end) p[j] = tile[wave * 16 + 4 * k + j][w.lane];
+    }
+  }
+}
+
+// detector of one band (deesser.rs:405-443): high-pass -> low-pass -> envelope; band 0's wave also keeps the broadband envelope
+template <int kBand>
+__device__ __forceinline__ void stage_de1_body(const StageArgs &a, const ChainParams &PW, int bx) {
+  const Who w = who(a, bx);
+  const DeEsserParams &D = PW.deesser;  // the window's own parameter block: the filters' crossfade counters as of its first sample
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  Ahead<float> in;
+  in.init(a.r.xi, w.g, w.lane, a.r.rows_f32, q_first);
+  Out<double> o_env, o_bb;
+  o_env.init(a.r.de_env[kBand], w.g, w.lane, a.r.rows_f64);
+  if (kBand == 0) o_bb.init(a.r.de_bb, w.g, w.lane, a.r.rows_f64);
+  const double *p = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.sc];
+  double env = p[0];
+  Bq hp{p[11 * w.NS], p[12 * w.NS], p[13 * w.NS], p[14 * w.NS]}, lp{p[15 * w.NS], p[16 * w.NS], p[17 * w.NS], p[18 * w.NS]};
+  double broadband_env = kBand == 0 ? a.st64[(int64_t)kDeBroadbandEnv * w.NS + w.sc] : 0.0;
+  const SectionParams sec_hp = D.bands[kBand].detector_hp, sec_lp = D.bands[kBand].detector_lp;  // by value (see stage A)
+  const double det_a = D.detector_attack_coeff, det_r = D.detector_release_coeff;
+  const bool any_xf = sec_hp.xf_remaining > 0 || sec_lp.xf_remaining > 0;
+  const BiquadCoef c_hp = sec_hp.xf_remaining > 0 ? sec_hp.pending : sec_hp.active, c_lp = sec_lp.xf_remaining > 0 ? sec_lp.pending : sec_lp.active;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const float(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      const float input = cur[u];
+      if (kBand == 0) {
+        broadband_env = smooth_value(broadband_env, (double)fabsf(input), det_a, det_r);
+        o_bb.v[u] = broadband_env;
+      }
+      float side;
+      if (any_xf) {  // (wave-uniform: a stream opens with at most a few hundred such samples)
+        const int64_t k = qb * kQ + u - n0;  // samples since the window's first
+        const int rem_hp = sec_hp.xf_remaining > k ? (int)(sec_hp.xf_remaining - k) : 0;
+        const int rem_lp = sec_lp.xf_remaining > k ? (int)(sec_lp.xf_remaining - k) : 0;
+        const float sc_hp = section_sample(sec_hp, rem_hp, input, hp);
+        side = section_sample(sec_lp, rem_lp, sc_hp, lp);
+      } else {
+        const float sc_hp = (float)direct(c_hp, (double)input, hp.z1, hp.z2);
+        side = (float)direct(c_lp, (double)sc_hp, lp.z1, lp.z2);
+      }
+      env = smooth_value(env, (double)fabsf(side), det_a, det_r);
+      o_env.v[u] = env;
+    };
+    run_block<false>(
+        qb, n0, n, 0, dummy, step,
+        [&] {
+          o_env.store_all(qb);
+          if (kBand == 0) o_bb.store_all(qb);
+        },
+        [&](int u) {
+          o_env.store_one(qb, u);
+          if (kBand == 0) o_bb.store_one(qb, u);
+        },
+        [] {});
+    in.template refill<kBuf>(qb);
+  });
+  if (w.valid) {
+    double *q = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.s];
+    q[0] = env;
+    q[11 * w.NS] = hp.z1; q[12 * w.NS] = hp.z2; q[13 * w.NS] = hp.pz1; q[14 * w.NS] = hp.pz2;
+    q[15 * w.NS] = lp.z1; q[16 * w.NS] = lp.z2; q[17 * w.NS] = lp.pz1; q[18 * w.NS] = lp.pz2;
+    if (kBand == 0) a.st64[(int64_t)kDeBroadbandEnv * w.NS + w.s] = broadband_env;
+  }
+}
+
+// levels in dB, voice reference, narrowness, dominance, confidence targets (deesser.rs:425-443,453-470,173-224)
+__device__ __forceinline__ void stage_de2_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
+  const ChainParams &P = preset(a, g);
+  const bool auto_enabled = P.deesser.auto_enabled != 0;
+  const int R = a.r.rows_f64;
+  const int64_t gb = (int64_t)g * R * kLanes;
+  const int i = threadIdx.x;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  double e0[kFfQuads], e1[kFfQuads], e2[kFfQuads], bb[kFfQuads];  // (loaded ahead of the arithmetic: see stage F5)
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    const int64_t row = gb + qoff(q0 + k, R) + i;
+    e0[k] = a.r.de_env[0][row];
+    e1[k] = a.r.de_env[1][row];
+    e2[k] = a.r.de_env[2][row];
+    bb[k] = a.r.de_bb[row];
+  }
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const int64_t row = gb + e.idx;
+    const double env[3] = {e0[k], e1[k], e2[k]};
+    double level_db[3];
+    double total_env = 0.0, max_env = 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      total_env += env[b];
+      max_env = fmax(max_env, env[b]);
+      level_db[b] = lin2db(env[b], 1e-10);
+    }
+    const double voice_level = fmax(bb[k] - total_env * kVoiceRefDiscount, 1e-8);
+    const double voice_db = lin2db(voice_level, 1e-10);
+    const double narrowness = total_env > 1e-10 ? max_env / total_env : 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const double side_db = level_db[b];
+      const double ratio_db = fmax(side_db - voice_db, 0.0);
+      const double dominance = max_env > 1e-10 ? sqrt(env[b] / max_env) : 0.0;
+      const double ct = confidence_target(side_db, voice_db, narrowness) * dominance;
+      a.r.de_ct[b][row] = dclamp(ct, 0.0, 1.0);
+      a.r.de_ratio[b][row] = ratio_db;
+      a.r.de_aux[b][row] = auto_enabled ? ((voice_db > -55.0 || side_db > -55.0) ? 1.0 : 0.0) : side_db;
+    }
+  }
+}
+
+// one band's confidence, baseline and raw reduction target (deesser.rs:453-517)
+template <int kBand>
+__device__ __forceinline__ void stage_de3_body(const StageArgs &a, int bx) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  const DeEsserParams &D = P.deesser;
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  const int R = a.r.rows_f64;
+  const double *r_ct = a.r.de_ct[kBand] + (int64_t)w.g * R * kLanes, *r_ratio = a.r.de_ratio[kBand] + (int64_t)w.g * R * kLanes;
+  const double *r_aux = a.r.de_aux[kBand] + (int64_t)w.g * R * kLanes;
+  double *r_tr = a.r.de_tr[kBand] + (int64_t)w.g * R * kLanes;
+  double *p = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.sc];
+  double confidence = p[w.NS], baseline = p[2 * w.NS];
+  // deesser.rs:445-451: the `auto` curve
+  const double amount = dclamp(D.auto_amount, 0.0, 1.0);
+  const double trigger_offset_db = lerp(8.0, 0.8, amount);
+  const double slope = lerp(0.08, 1.9, amount);
+  const double auto_cap = lerp(0.8, 14.0, amount);
+  const double confidence_floor = lerp(0.28, 0.06, amount);
+  const double cap_db = fmin(auto_cap, D.max_reduction_db * 0.75);
+  const double det_a = D.detector_attack_coeff, det_r = D.detector_release_coeff;
+  const double baseline_fall = D.baseline_fall, baseline_rise = D.baseline_rise, baseline_inactive = D.baseline_inactive;
+  const double threshold_db = D.threshold_db, ratio = D.ratio, max_reduction_db = D.max_reduction_db;
+  const bool auto_enabled = D.auto_enabled != 0;
+  const double cg_start = dclamp(confidence_floor, 0.0, 0.95);
+  // quad by quad, the loads two quads ahead (three f64 inputs: whole blocks of sixteen per input would not fit the registers)
+  struct Slot {
+    Quad<double> ct, ratio, aux;
+  };
+  auto fetch = [&](int64_t q) {
+    const int64_t o = qoff(q, R) + w.lane * kQ;
+    return Slot{load_quad(r_ct + o), load_quad(r_ratio + o), load_quad(r_aux + o)};
+  };
+  const int64_t n_end = n0 + n;
+  Slot s0 = fetch(q_first), s1 = fetch(q_first + 1);
+  for (int64_t q = q_first; q <= q_last; ++q) {
+    const Slot cur = s0;
+    s0 = s1;
+    s1 = fetch(q + 2);
+    double out[kQ];
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) {
+      const int64_t na = q * kQ + j;
+      out[j] = 0.0;
+      if (na < n0 || na >= n_end) continue;
+      const double ratio_db = cur.ratio.v[j];
+      confidence = smooth_value(confidence, cur.ct.v[j], det_a, det_r);
+      double tr = 0.0;
+      if (auto_enabled) {
+        const bool voice_active = cur.aux.v[j] != 0.0;
+        if (voice_active) {
+          const double bt = dclamp(ratio_db * 0.45, 0.0, 24.0);
+          const double bc = bt < baseline ? baseline_fall : baseline_rise;
+          baseline = bc * baseline + (1.0 - bc) * bt;
+        } else {
+          baseline *= baseline_inactive;
+        }
+        const double cg = normalize_range(confidence, cg_start, 1.0);
+        const double over = fmax(ratio_db - baseline - trigger_offset_db, 0.0);
+        tr = dclamp(over * slope * cg, 0.0, cap_db);
+      } else {
+        const double side_db = cur.aux.v[j];
+        if (side_db > threshold_db) {
+          const double ratio_threshold = dclamp((threshold_db + 60.0) * 0.10, 0.0, 6.0);
+          const double level_over = side_db - threshold_db;
+          const double ratio_over = ratio_db - ratio_threshold;
+          if (ratio_over > 0.0) {
+            const double over = fmin(level_over, ratio_over);
+            const double cg = normalize_range(confidence, 0.22, 1.0);
+            tr = dclamp((1.0 - (1.0 / ratio)) * over * cg, 0.0, max_reduction_db * 0.75);
+          }
+        }
+      }
+      out[j] = tr;
+    }
+    double *pd = r_tr + qoff(q, R) + w.lane * kQ;
+    if (q * kQ >= n0 && q * kQ + 3 < n_end) {
+      *reinterpret_cast<double2 *>(pd) = make_double2(out[0], out[1]);
+      *reinterpret_cast<double2 *>(pd + 2) = make_double2(out[2], out[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (q * kQ + j >= n0 && q * kQ + j < n_end) pd[j] = out[j];
+    }
+  }
+  if (w.valid) {
+    double *q = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.s];
+    q[w.NS] = confidence;
+    q[2 * w.NS] = baseline;
+  }
+}
+
+// target scaling, reduction smoothing, the 0.001 dB hold on the dynamic EQs' gains (deesser.rs:518-538), the block's figure
+__device__ __forceinline__ void stage_de4_body(const StageArgs &a, int bx) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  const DeEsserParams &D = P.deesser;
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = a.n, n0 = a.n0;
+  const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
+  const int R = a.r.rows_f64, R32 = a.r.rows_f32;
+  const double *r_tr[3];
+  double *r_g[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    r_tr[b] = a.r.de_tr[b] + (int64_t)w.g * R * kLanes;
+    r_g[b] = a.r.de_gdb[b] + (int64_t)w.g * R * kLanes;
+  }
+  float *r_upd = a.r.de_upd + (int64_t)w.g * R32 * kLanes;
+  double red[3], gdb[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const double *p = &a.st64[(int64_t)(kDeBand0 + b * kDeBandStride) * w.NS + w.sc];
+    red[b] = p[3 * w.NS];
+    gdb[b] = p[4 * w.NS];
+  }
+  const double max_reduction_db = D.max_reduction_db, attack = D.attack_coeff, release = D.release_coeff;
+  double current_reduction = a.st64[(int64_t)kDeCurrentReduction * w.NS + w.sc];
+  const int cb = P.control_block;
+  BlockStats *stats = a.stats;
+  int in_block = 0;
+  int64_t blk = 0;
+  struct Slot {
+    Quad<double> t[3];
+  };
+  auto fetch = [&](int64_t q) {
+    const int64_t o = qoff(q, R) + w.lane * kQ;
+    return Slot{{load_quad(r_tr[0] + o), load_quad(r_tr[1] + o), load_quad(r_tr[2] + o)}};
+  };
+  const int64_t n_end = n0 + n;
+  Slot s0 = fetch(q_first), s1 = fetch(q_first + 1);
+  for (int64_t q = q_first; q <= q_last; ++q) {
+    const Slot cur = s0;
+    s0 = s1;
+    s1 = fetch(q + 2);
+    double og[3][kQ];
+    float ou[kQ];
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) {
+      const int64_t na = q * kQ + j;
+      ou[j] = 0.0f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) og[b][j] = 0.0;
+      if (na < n0 || na >= n_end) continue;
+      double target[3] = {cur.t[0].v[j], cur.t[1].v[j], cur.t[2].v[j]};
+      double target_sum = 0.0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) target_sum += target[b];
+      if (target_sum > max_reduction_db && target_sum > 0.0) {
+        const double scale = max_reduction_db / target_sum;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) target[b] *= scale;
+      }
+      double total_reduction = 0.0;
+      int upd = 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        red[b] = smooth_value(red[b], target[b], attack, release);
+        total_reduction += red[b];
+        const double gain = -red[b];
+        if (fabs(gdb[b] - gain) > 0.001) {  // set_gain_db_immediate (deesser.rs:536-538)
+          gdb[b] = gain;
+          upd |= 1 << b;
+        }
+        og[b][j] = gdb[b];
+      }
+      current_reduction = fmin(total_reduction, max_reduction_db);
+      ou[j] = (float)upd;
+      in_block += 1;
+      if (in_block == cb || na + 1 == n_end) {  // (wave-uniform) a control block, or the window, ends with this sample
+        if (w.valid && stats) stats[blk * w.NS + w.s].deesser_gr_db = (float)current_reduction;
+        blk += 1;
+        in_block = 0;
+      }
+    }
+    const int64_t o64 = qoff(q, R) + w.lane * kQ, o32 = qoff(q, R32) + w.lane * kQ;
+    if (q * kQ >= n0 && q * kQ + 3 < n_end) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        *reinterpret_cast<double2 *>(r_g[b] + o64) = make_double2(og[b][0], og[b][1]);
+        *reinterpret_cast<double2 *>(r_g[b] + o64 + 2) = make_double2(og[b][2], og[b][3]);
+      }
+      *reinterpret_cast<float4 *>(r_upd + o32) = make_float4(ou[0], ou[1], ou[2], ou[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (q * kQ + j >= n0 && q * kQ + j < n_end) {
+#pragma unroll
+          for (int b = 0; b < 3; ++b) r_g[b][o64 + j] = og[b][j];
+          r_upd[o32 + j] = ou[j];
+        }
+    }
+  }
+  if (w.valid) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double *q = &a.st64[(int64_t)(kDeBand0 + b * kDeBandStride) * w.NS + w.s];
+      q[3 * w.NS] = red[b];
+      q[4 * w.NS] = gdb[b];
+    }
+    a.st64[(int64_t)kDeCurrentReduction * w.NS + w.s] = current_reduction;
+  }
+}
+
+// the peaking coefficients of every gain that changed (Biquad::calculate_coefficients, biquad.rs:109-182)
+__device__ __forceinline__ void stage_de5_body(const StageArgs &a, int bx, int by) {
+  const int g = by;
+  const ChainParams &P = preset(a, g);
+  const DeEsserParams &D = P.deesser;
+  const int R = a.r.rows_f64, R32 = a.r.rows_f32;
+  const int64_t gb = (int64_t)g * R * kLanes, gb32 = (int64_t)g * R32 * kLanes;
+  const int i = threadIdx.x;
+  const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
+  float upd[kFfQuads];
+  double gd[3][kFfQuads];
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    upd[k] = a.r.de_upd[gb32 + qoff(q0 + k, R32) + i];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) gd[b][k] = a.r.de_gdb[b][gb + qoff(q0 + k, R) + i];
+  }
+#pragma unroll
+  for (int k = 0; k < kFfQuads; ++k) {
+    const Elem e = ff_elem(a, q0 + k, i, R);
+    if (!e.in) continue;
+    const int64_t row = gb + e.idx;
+    const int bits = (int)upd[k];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      if (bits & (1 << b)) {
+        const BiquadCoef c = peaking(D.bands[b].dyn_cos_omega, D.bands[b].dyn_alpha, gd[b][k]);
+        a.r.de_c[b][0][row] = c.b0;
+        a.r.de_c[b][1][row] = c.b1;
+        a.r.de_c[b][2][row] = c.b2;
+        a.r.de_c[b][3][row] = c.a1;
+        a.r.de_c[b][4][row] = c.a2;
+      }
+  }
+}
+
+// one dynamic EQ of the cascade (deesser.rs:526-546): band 0 reads the chain input, band i the output of band i - 1.
+// Quad by quad with the loads two quads ahead (five coefficient rings: whole blocks of sixteen would not fit the registers).
+template <int kBand>
+__device__ __forceinline__ void stage_de6_body(const StageArgs &a, const ChainParams &PW, int bx) {
+  const Who w = who(a, bx);
+  const SectionParams sec = PW.deesser.bands[kBand].dynamic_eq;  // the window's own block (crossfade counters as of its first sample)
+  __builtin_amdgcn_s_setprio(3);
+  const int R = a.r.rows_f64, R32 = a.r.rows_f32;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t q_first = n0 >> 2, q_last = (n_end - 1) >> 2;
+  const float *src = (kBand == 0 ? a.r.xi : a.r.de_y[kBand - 1]) + (int64_t)w.g * R32 * kLanes;
+  const float *updr = a.r.de_upd + (int64_t)w.g * R32 * kLanes;
+  float *dst = a.r.de_y[kBand] + (int64_t)w.g * R32 * kLanes;
+  const double *cr[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) cr[j] = a.r.de_c[kBand][j] + (int64_t)w.g * R * kLanes;
+  double *p = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.sc];
+  double cancelled = p[5 * w.NS];
+  BiquadCoef dyn{p[6 * w.NS], p[7 * w.NS], p[8 * w.NS], p[9 * w.NS], p[10 * w.NS]};
+  Bq eq{p[19 * w.NS], p[20 * w.NS], p[21 * w.NS], p[22 * w.NS]};
+  struct Slot {
+    Quad<float> x, u;
+    Quad<double> c[5];
+  };
+  auto fetch = [&](int64_t q) {
+    Slot s;
+    const int64_t o32 = qoff(q, R32) + w.lane * kQ, o64 = qoff(q, R) + w.lane * kQ;
+    s.x = load_quad(src + o32);
+    s.u = load_quad(updr + o32);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s.c[j] = load_quad(cr[j] + o64);
+    return s;
+  };
+  Slot s0 = fetch(q_first), s1 = fetch(q_first + 1);
+  for (int64_t q = q_first; q <= q_last; ++q) {
+    const Slot cur = s0;
+    s0 = s1;
+    s1 = fetch(q + 2);
+    float y[kQ];
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) {
+      const int64_t na = q * kQ + j;
+      y[j] = 0.0f;
+      if (na < n0 || na >= n_end) continue;
+      if (((int)cur.u.v[j]) & (1 << kBand)) {  // set_coefficients_immediate: new coefficients, a pending crossfade is cancelled
+        dyn = BiquadCoef{cur.c[0].v[j], cur.c[1].v[j], cur.c[2].v[j], cur.c[3].v[j], cur.c[4].v[j]};
+        cancelled = 1.0;
+        eq.pz1 = 0.0;
+        eq.pz2 = 0.0;
+      }
+      const int64_t k = na - n0;
+      const int rem = sec.xf_remaining > k ? (int)(sec.xf_remaining - k) : 0;
+      if (rem > 0 && cancelled == 0.0) {
+        y[j] = section_sample(sec, rem, cur.x.v[j], eq);
+        if (rem == 1) dyn = sec.pending;
+      } else {
+        y[j] = (float)direct(dyn, (double)cur.x.v[j], eq.z1, eq.z2);
+      }
+    }
+    float *pd = dst + qoff(q, R32) + w.lane * kQ;
+    if (q * kQ >= n0 && q * kQ + 3 < n_end) {
+      *reinterpret_cast<float4 *>(pd) = make_float4(y[0], y[1], y[2], y[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (q * kQ + j >= n0 && q * kQ + j < n_end) pd[j] = y[j];
+    }
+  }
+  if (w.valid) {
+    double *qd = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.s];
+    qd[5 * w.NS] = cancelled;
+    qd[6 * w.NS] = dyn.b0; qd[7 * w.NS] = dyn.b1; qd[8 * w.NS] = dyn.b2; qd[9 * w.NS] = dyn.a1; qd[10 * w.NS] = dyn.a2;
+    qd[19 * w.NS] = eq.z1; qd[20 * w.NS] = eq.z2; qd[21 * w.NS] = eq.pz1; qd[22 * w.NS] = eq.pz2;
+  }
+}
+
 // ---- all stages of one launch step as roles of TWO dispatches (DiagArgs, af_stages.h): the serial stages (and the
 // one-wave-per-block wide one) in workgroups of one wave, the wide stages in workgroups of four.  (One dispatch for both kinds
 // costs the wide stages their occupancy -- the serial stages' ~250 registers per lane become every workgroup's: 256 streams
@@ -1312,8 +1791,8 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   const float *lim_in = comp ? a.r.xc : a.r.xe;
   switch (role.stage) {
     case kStEq: {
-      EqSystolicArgs ea{d.params_eq + role.win.eq_slot, a.group_preset, a.st64, a.in, nullptr, a.r.xe, a.r.xi, nullptr,
-                        a.n, a.stream_stride, a.n0, a.n_streams, a.r.rows_f32};
+      EqSystolicArgs ea{d.params_eq + role.win.eq_slot, a.group_preset, a.st64, a.in, nullptr, a.r.xe, d.deesser ? nullptr : a.r.xi, nullptr,
+                        a.n, a.stream_stride, a.n0, a.n_streams, a.r.rows_f32, nullptr, d.deesser ? a.r.de_y[2] : nullptr};
       if (role.win.eq_crossfade) eq_systolic_body<false, true>(ea, bx);
       else eq_systolic_body<false, false>(ea, bx);
       break;
@@ -1351,7 +1830,30 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   }
 }
 
+// the de-esser's serial stages: a dispatch of their own (inside the kernel above their registers would be every role's)
+__global__ __launch_bounds__(64) void stage_diag_deesser_kernel(DiagArgs d) {
+  const RolePick pk = pick_role(d);
+  const DiagRole &role = d.roles[pk.r];
+  const StageArgs a = role_args(d, role);
+  const int bx = pk.bx;
+  const ChainParams &PW = d.params_eq[role.win.eq_slot];  // the window's own parameter block
+  switch (role.stage) {
+    case kStDe1a: stage_de1_body<0>(a, PW, bx); break;
+    case kStDe1b: stage_de1_body<1>(a, PW, bx); break;
+    case kStDe1c: stage_de1_body<2>(a, PW, bx); break;
+    case kStDe3a: stage_de3_body<0>(a, bx); break;
+    case kStDe3b: stage_de3_body<1>(a, bx); break;
+    case kStDe3c: stage_de3_body<2>(a, bx); break;
+    case kStDe4: stage_de4_body(a, bx); break;
+    case kStDe6a: stage_de6_body<0>(a, PW, bx); break;
+    case kStDe6b: stage_de6_body<1>(a, PW, bx); break;
+    case kStDe6c: stage_de6_body<2>(a, PW, bx); break;
+    default: break;
+  }
+}
+
 __global__ __launch_bounds__(256) void stage_diag_wide_kernel(DiagArgs d) {
+  __shared__ float tile[kTileRows][kLanes + 1];  // the transposing stages' (F6, De0) 64-step tile
   const RolePick pk = pick_role(d);
   const DiagRole &role = d.roles[pk.r];
   const StageArgs a = role_args(d, role);
@@ -1365,7 +1867,10 @@ __global__ __launch_bounds__(256) void stage_diag_wide_kernel(DiagArgs d) {
     case kStF3: stage_f3_body(a, bx, by); break;
     case kStF3a: stage_f3a_body(a, bx, by); break;
     case kStF5: stage_f5_body(a, lim_in, bx, by); break;
-    case kStF6: stage_f6_body(a, bx, by); break;
+    case kStF6: stage_f6_body(a, tile, bx, by); break;
+    case kStDe0: stage_de0_body(a, tile, d.flags, bx, by); break;
+    case kStDe2: stage_de2_body(a, bx, by); break;
+    case kStDe5: stage_de5_body(a, bx, by); break;
     default: break;
   }
 }
@@ -1380,16 +1885,25 @@ unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, 
   *gy = groups;
   switch (stage) {
     case kStEq: *gy = 1; return (unsigned)((n_streams + 3) / 4);  // four streams per wave
-    case kStF1: case kStF2: case kStF3: case kStF3a: case kStFR: return (quads + kFfQuads - 1) / kFfQuads;
+    case kStF1: case kStF2: case kStF3: case kStF3a: case kStFR: case kStDe2: case kStDe5: return (quads + kFfQuads - 1) / kFfQuads;
     case kStF4: return (unsigned)(n / (w_min > 0 ? w_min : 1) + 2);
-    case kStF5: case kStF6: return tiles;
+    case kStF5: case kStF6: case kStDe0: return tiles;
     default: *gy = 1; return groups;  // serial stages: one workgroup (its first wave) per group
   }
 }
 
-hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, bool wide, hipStream_t stream) {
+int stage_dispatch_kind(int stage) {
+  switch (stage) {
+    case kStF1: case kStF2: case kStFR: case kStF3: case kStF3a: case kStF5: case kStF6: case kStDe0: case kStDe2: case kStDe5: return 1;
+    case kStDe1a: case kStDe1b: case kStDe1c: case kStDe3a: case kStDe3b: case kStDe3c: case kStDe4: case kStDe6a: case kStDe6b: case kStDe6c: return 2;
+    default: return 0;
+  }
+}
+
+hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, int kind, hipStream_t stream) {
   if (total_blocks == 0) return hipSuccess;
-  if (wide) hipLaunchKernelGGL(stage_diag_wide_kernel, dim3(total_blocks), dim3(256), 0, stream, d);
+  if (kind == 1) hipLaunchKernelGGL(stage_diag_wide_kernel, dim3(total_blocks), dim3(256), 0, stream, d);
+  else if (kind == 2) hipLaunchKernelGGL(stage_diag_deesser_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
   else hipLaunchKernelGGL(stage_diag_serial_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
   return hipGetLastError();
 }

@@ -18,7 +18,7 @@ MAX_ABS = 5e-7
 MAX_RMS = 5e-8
 
 
-@pytest.fixture(scope="module", params=["quad", "ring-16x4", "lane"])
+@pytest.fixture(scope="module", params=["quad", "ring-16x4", "lane", "staged"])
 def mi(request):
     import mic_eq_mi
 
@@ -107,6 +107,9 @@ def test_deesser_orders_and_manual_mode(mi, oracle, eq_first, auto):
     band (a pending coefficient crossfade on the nine de-esser filters), ragged batch and block sizes."""
     if eq_first and os.environ["AF_KERNEL_VARIANT"] in ("lane", "quad"):
         pytest.skip("EQ-before-de-esser needs the ring kernel's pre-pass")
+    if os.environ["AF_KERNEL_VARIANT"] == "staged":
+        pytest.skip("this test runs the realtime front end without the suppressor (kernels 1-3); the stage pipeline's de-esser "
+                    "stages have test_deesser_stages_equal_the_lane_kernel below")
     L = oracle.lib()
     n_streams, n = 67, 48_000 + 333
     audio = np.stack([S.kat_signal(101, *S.stream_params(s))[:n] for s in range(n_streams)])
@@ -154,3 +157,71 @@ def test_deesser_orders_and_manual_mode(mi, oracle, eq_first, auto):
     assert worst[0] <= MAX_ABS and worst[1] <= MAX_RMS, worst
     assert any_reduction > 0.5  # the de-esser really acted
     eng.close()
+
+
+@pytest.mark.parametrize("auto", [True, False])
+def test_deesser_stages_equal_the_lane_kernel(oracle, auto):
+    """The de-esser as stages of the stage pipeline (af_stages.hip: loader | three detectors | levels and confidence targets |
+    three confidence / baseline recurrences | scaling + reduction smoothing + gain hold | coefficients | three cascaded dynamic
+    EQs) against the lane-per-stream pass: the same expressions on the same state rows, so audio and block rows agree BIT FOR
+    BIT -- auto and threshold / ratio modes, moved detector band (a pending coefficient crossfade on the nine de-esser filters),
+    ragged batch, ragged control block, a call that ends inside a block; AUTO routes the configuration to the stages."""
+    import mic_eq_mi as mi
+
+    n_streams, n = 67, 24_000 + 333
+    audio = np.stack([S.kat_signal(51, *S.stream_params(s))[:n] for s in range(n_streams)])
+
+    def run(kernel):
+        previous = os.environ.pop("AF_KERNEL_VARIANT", None)
+        try:
+            eng = mi.Engine(48_000.0, n_streams)
+        finally:
+            if previous is not None:
+                os.environ["AF_KERNEL_VARIANT"] = previous
+        for what in ("deesser_enabled", "eq_enabled", "compressor_enabled", "limiter_enabled"):
+            getattr(eng, "set_" + what)(1)
+        eng.set_input_clamp_enabled(1)
+        eng.deesser_set_auto_enabled(int(auto)); eng.deesser_set_auto_amount(0.7)
+        eng.deesser_set_low_cut_hz(3500.0); eng.deesser_set_high_cut_hz(9000.0)
+        eng.deesser_set_threshold_db(-40.0); eng.deesser_set_ratio(6.0)
+        eng.deesser_set_attack_ms(1.0); eng.deesser_set_release_ms(60.0)
+        eng.deesser_set_max_reduction_db(8.0)
+        eng.eq_set_band_gain(7, 4.0)
+        eng.compressor_set_threshold(-24.0)
+        eng.set_control_block_samples(441)
+        eng.set_kernel(kernel)
+        outs, rows, used = [], [], []
+        for lo, hi in ((0, 10_000), (10_000, n)):
+            outs.append(eng.process(audio[:, lo:hi]))
+            rows.append(eng.block_stats().copy())
+            used.append(eng.last_kernel())
+        eng.close()
+        return np.concatenate(outs, axis=1), np.concatenate(rows, axis=0), used
+
+    lane = run(1)
+    auto_routed = run(0)
+    assert set(lane[2]) == {1} and set(auto_routed[2]) == {4}, (lane[2], auto_routed[2])
+    assert np.array_equal(lane[0].view(np.uint32), auto_routed[0].view(np.uint32)), float(np.abs(lane[0] - auto_routed[0]).max())
+    for name in lane[1].dtype.names:
+        assert lane[1][name].tobytes() == auto_routed[1][name].tobytes(), name
+    assert float(lane[1]["deesser_gain_reduction_db"].max()) > 0.5  # the de-esser really acted
+    # ... and against the oracle, as every kernel
+    chain = oracle.Chain(48_000.0)
+    L = oracle.lib()
+    for what in ("deesser_enabled", "eq_enabled", "compressor_enabled", "limiter_enabled"):
+        chain.set(what, 1)
+    d = chain.deesser
+    L.afo_deesser_set_auto_enabled(d, int(auto)); L.afo_deesser_set_auto_amount(d, 0.7)
+    L.afo_deesser_set_low_cut_hz(d, 3500.0); L.afo_deesser_set_high_cut_hz(d, 9000.0)
+    L.afo_deesser_set_threshold_db(d, -40.0); L.afo_deesser_set_ratio(d, 6.0)
+    L.afo_deesser_set_attack_ms(d, 1.0); L.afo_deesser_set_release_ms(d, 60.0)
+    L.afo_deesser_set_max_reduction_db(d, 8.0)
+    L.afo_eq_set_band_gain(chain.eq, 7, 4.0)
+    L.afo_compressor_set_threshold(chain.compressor, -24.0)
+    want = np.clip(audio[66], -1.0, 1.0).copy()
+    pos = 0
+    while pos < n:
+        chain.process_block(want[pos : pos + 441])
+        pos += 441
+    e = _err(auto_routed[0][66], want)
+    assert e[0] <= MAX_ABS and e[1] <= MAX_RMS, e

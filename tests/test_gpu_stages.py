@@ -147,9 +147,14 @@ def test_unsupported_configurations_are_refused(core):
         settings["eq_bands_v2"] = TYPED_BANDS
         core.configure_auto_eq_chain(eng, 48_000.0, S.LIMITER_BANDS, settings)
         eng.set_deesser_enabled(1)
+        eng.set_eq_before_deesser(1)  # (the de-esser ahead of the EQ is built as stages since round 3; this order is not)
         eng.set_kernel(_lib.KERNEL_STAGED)
         with pytest.raises(NotImplementedError, match="stage pipeline"):
             eng.process(S.batch_signal(2, 2))
+        eng.reset()
+        eng.set_eq_before_deesser(0)
+        eng.process(S.batch_signal(2, 2))
+        assert eng.last_kernel() == _lib.KERNEL_STAGED
     finally:
         eng.close()
 
@@ -284,3 +289,44 @@ def test_engine_reuse_after_reset_with_shorter_control_blocks(core):
     finally:
         fresh.close()
     assert_same(got, want)
+
+
+def test_baseline_configs1_shape_on_auto(oracle):
+    """BASELINE configs[1] at its own shape -- 256 streams x 10 s, EQ + compressor + limiter + true-peak limiter, no suppressor --
+    on AUTO (which routes it to the stage pipeline): sixteen streams spread over the batch against the CPU oracle, determinism,
+    energy bookkeeping of the block rows against the audio."""
+    import torch
+
+    import bench
+    from mic_eq_mi import mic_eq_core as core
+
+    streams, seconds = 256, 10
+    dev = torch.device("cuda", 0)
+    x = bench.synth_batch(streams, seconds * 100, 0, dev)
+    n = x.shape[1]
+
+    def run():
+        y = torch.empty_like(x)
+        eng = core.Engine(48_000.0, streams, 0)
+        core.configure_auto_eq_chain(eng, 48_000.0, bench.BANDS, bench.CHAIN_SETTINGS)
+        eng.process_device(x.data_ptr(), y.data_ptr(), n, n, 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        rows, used = eng.block_stats(), eng.last_kernel()
+        eng.close()
+        return y, rows, used
+
+    y, rows, used = run()
+    assert used == 4  # AF_KERNEL_STAGED
+    y2, _, _ = run()
+    assert torch.equal(y, y2)
+    assert rows.shape == (seconds * 50, streams)
+    assert np.allclose(rows["output_square_sum"].sum(axis=0), (y.double() ** 2).sum(dim=1).cpu().numpy(), rtol=1e-9)
+    sample = sorted({0, 1, 63, 64, 127, 128, 255} | {int(v) for v in np.linspace(0, streams - 1, 12)})
+    assert len(sample) >= 16
+    worst = (0.0, 0.0)
+    for s in sample:
+        want = oracle.simulate_auto_eq_chain(x[s].cpu().numpy(), 48_000, bench.BANDS, dict(bench.CHAIN_SETTINGS, return_output_audio=True))["output_audio"]
+        d = y[s].cpu().numpy().astype(np.float64) - want.astype(np.float64)
+        worst = (max(worst[0], float(np.max(np.abs(d)))), max(worst[1], float(np.sqrt(np.mean(d * d)))))
+    print(f"configs[1] on AUTO (stage pipeline): {len(sample)} streams vs oracle, worst |err| {worst[0]:.3e}, worst RMS {worst[1]:.3e}")
+    assert worst[0] <= 2e-7 and worst[1] <= 2e-8, worst
