@@ -917,12 +917,12 @@ int stage_pipe_prepare(af_engine *e, int64_t tw_max) {
     AF_HIP(ring64(p));
   if (deesser) {
     for (int b = 0; b < 3; ++b) {
-      for (double **p : {&r.de_env[b], &r.de_ct[b], &r.de_ratio[b], &r.de_aux[b], &r.de_tr[b], &r.de_gdb[b]}) AF_HIP(ring64(p));
+      for (double **p : {&r.de_env[b], &r.de_ct[b], &r.de_ratio[b], &r.de_aux[b], &r.de_tr[b], &r.de_gdb[b], &r.de_red[b]}) AF_HIP(ring64(p));
+      AF_HIP(ring32(&r.de_upd[b]));
       for (int j = 0; j < 5; ++j) AF_HIP(ring64(&r.de_c[b][j]));
       AF_HIP(ring32(&r.de_y[b]));
     }
     AF_HIP(ring64(&r.de_bb));
-    AF_HIP(ring32(&r.de_upd));
   }
   sp.with_deesser = deesser;
   sp.tw_max = tw_max;
@@ -949,12 +949,12 @@ int stage_pipe_clear(af_engine *e) {  // a fresh engine: the histories are zeros
     AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
   if (sp.with_deesser) {
     for (int b = 0; b < 3; ++b) {
-      for (double *p : {r.de_env[b], r.de_ct[b], r.de_ratio[b], r.de_aux[b], r.de_tr[b], r.de_gdb[b]}) AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+      for (double *p : {r.de_env[b], r.de_ct[b], r.de_ratio[b], r.de_aux[b], r.de_tr[b], r.de_gdb[b], r.de_red[b]}) AF_HIP(hipMemset(p, 0, sizeof(double) * r.rows_f64 * 64 * groups));
+      AF_HIP(hipMemset(r.de_upd[b], 0, sizeof(float) * r.rows_f32 * 64 * groups));
       for (int j = 0; j < 5; ++j) AF_HIP(hipMemset(r.de_c[b][j], 0, sizeof(double) * r.rows_f64 * 64 * groups));
       AF_HIP(hipMemset(r.de_y[b], 0, sizeof(float) * r.rows_f32 * 64 * groups));
     }
     AF_HIP(hipMemset(r.de_bb, 0, sizeof(double) * r.rows_f64 * 64 * groups));
-    AF_HIP(hipMemset(r.de_upd, 0, sizeof(float) * r.rows_f32 * 64 * groups));
   }
   sp.windows = 0;
   return AF_OK;
@@ -1002,17 +1002,20 @@ StagePlan stage_plan(const af::ChainParams &run) {
   int at = 0;
   if (run.flags & af::kFlagDeesser) {
     // the de-esser ahead of the EQ (deesser.rs:405-547): transposing loader | three detectors | levels and confidence targets |
-    // three confidence / baseline recurrences | scaling, reduction smoothing, gain hold | coefficients | three cascaded dynamic EQs
+    // three confidence / baseline recurrences | target scaling | three reduction smoothers with the gain hold | coefficients
+    // (and the block's figure) | three cascaded dynamic EQs
     add(af::kStDe0, 0);
     for (int k : {af::kStDe1a, af::kStDe1b, af::kStDe1c}) add(k, 1);
     add(af::kStDe2, 2);
     for (int k : {af::kStDe3a, af::kStDe3b, af::kStDe3c}) add(k, 3);
-    add(af::kStDe4, 4);
-    add(af::kStDe5, 5);
-    add(af::kStDe6a, 6);
-    add(af::kStDe6b, 7);
-    add(af::kStDe6c, 8);
-    at = add(af::kStEq, 9);
+    add(af::kStDe4s, 4);
+    for (int k : {af::kStDe4a, af::kStDe4b, af::kStDe4c}) add(k, 5);
+    add(af::kStDe4t, 6);
+    add(af::kStDe5, 6);
+    add(af::kStDe6a, 7);
+    add(af::kStDe6b, 8);
+    add(af::kStDe6c, 9);
+    at = add(af::kStEq, 10);
   } else {
     at = add(af::kStEq, 0);
   }
@@ -1058,6 +1061,11 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
   d.auto_makeup = (run.flags & af::kFlagCompressor) && run.comp.auto_makeup_enabled;
   d.base.stream_stride = sp.call_stride;
   d.deesser = (run.flags & af::kFlagDeesser) ? 1 : 0;
+  static const int debug_skip = [] {  // AF_STAGE_SKIP=<StageId>: timing probe (that stage does nothing; results are garbage)
+    const char *env = std::getenv("AF_STAGE_SKIP");
+    return env ? std::atoi(env) : -1;
+  }();
+  d.debug_skip = debug_skip;
   // two dispatches per step: the one-wave workgroups (serial stages and F4), then the wide stages; with the de-esser a third
   // for its serial stages
   for (int pass = 0; pass < (d.deesser ? 3 : 2); ++pass) {
@@ -1872,6 +1880,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       const char *env = std::getenv("AF_ORDER_PITCH");
       return env && std::atoi(env) != 0;  // off: it only moves the starvation to the resynthesis kernel (313 vs 296 ms)
     }();
+    // ORDERING THAT IS LOAD-BEARING: the pitch search of window w + 1 and the pitch tracker of window w must stay on this ONE
+    // stream, in this order.  The whitened pitch buffers (`d_ds`, 3.4 KB per frame and stream) are a single set: the tracker of
+    // window w reads what the search of window w wrote, and nothing but stream order keeps the search of w + 1 from overwriting
+    // it first.  (Round 2 moved the tracker to the pre-pass stream to shorten this stream: run-to-run bit-identity was lost --
+    // that race.  Moving either kernel needs a second `d_ds` set and an event from the tracker to the next search.)  The
+    // tracker also owns the stream's pitch state rows (last period / gain, cepstral ring, the 1728-sample history a NEW call's
+    // first pre-pass reads: ordered through the caller's stream at the end of the call).
     AF_HIP(af::launch_suppressor_analysis(window_args(f0, nf, w), e->supp.tables, e->ana_stream,
                                           (order_pitch && w >= 1) ? rnn_done[w - 1] : nullptr));
     AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));

@@ -865,8 +865,24 @@ struct alignas(16) PitchSearch4Lds {
     PsScan scan[kPsFrames];
   };
 };
+// Development aid (make EXTRA=-DAF_PS_PROFILE): shader-cycle stamps at the phase boundaries of the pitch search, printed by wave
+// 0 of workgroup 0 and of one workgroup in the middle of the grid.
+#ifdef AF_PS_PROFILE
+#define AF_PS_DECL long long ps_t[9]; ps_t[8] = clock64()
+#define AF_PS_STAMP(k) ps_t[k] = clock64()
+#define AF_PS_PRINT                                                                                                        \
+  if (lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))                                          \
+  printf("pitch search wg %u: span %lld | decimate %lld | autocorr+lpc %lld | whiten+store %lld | coarse xcorr %lld | coarse scan %lld | " \
+         "fine xcorr %lld | fine scan %lld | total %lld cycles\n", blockIdx.x, ps_t[0] - ps_t[8], ps_t[1] - ps_t[0], ps_t[2] - ps_t[1],     \
+         ps_t[3] - ps_t[2], ps_t[4] - ps_t[3], ps_t[5] - ps_t[4], ps_t[6] - ps_t[5], ps_t[7] - ps_t[6], ps_t[7] - ps_t[8])
+#else
+#define AF_PS_DECL
+#define AF_PS_STAMP(k)
+#define AF_PS_PRINT
+#endif
 extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch4_kernel(SuppArgs a, SuppTables tb) {
   __shared__ PitchSearch4Lds L;
+  AF_PS_DECL;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int groups = (a.n_frames + kPsFrames - 1) / kPsFrames;
   const int s = (int)(blockIdx.x / groups), f0 = (int)(blockIdx.x % groups) * kPsFrames;
@@ -883,6 +899,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     for (int i = tid; i < span / 4; i += 64 * kPsFrames) dst[i] = src[i];
   }
   __syncthreads();
+  AF_PS_STAMP(0);  // span in LDS
   float *ds = L.ds[wave];
   if (live) {
     const float *pb = L.raw + wave * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
@@ -892,6 +909,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   }
   __syncthreads();  // every wave has left the span: its LDS now holds the scan arrays
   if (!live) return;
+  AF_PS_STAMP(1);  // decimated
   PsScan &S = L.scan[wave];
   const int64_t cell = (int64_t)f * a.n_streams + s;
   SuppFrameRec *rec = a.rec + cell;
@@ -933,6 +951,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     n3 = lpc[3] + c1 * lpc[2];
     n4 = c1 * lpc[3];
   }
+  AF_PS_STAMP(2);  // autocorrelation + LPC
   {
     // celt_fir5 with zero initial memory: y[i] = x[i] + n0 x[i-1] + ... + n4 x[i-5], in that order
     float yv[14];
@@ -956,6 +975,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     float *dsg = a.ds + cell * (kPitchBuf / 2);
     for (int i = lane; i < kPitchBuf / 2; i += 64) dsg[i] = ds[i];
   }
+  AF_PS_STAMP(3);  // whitened + stored
   // ---------------- pitch_search(x_lp = ds + 384, y = ds, len 960, max_pitch 588)
   const int max_pitch = kPitchMax - 3 * kPitchMin;  // 588
   const float *x_lp = ds + (kPitchMax >> 1);
@@ -992,6 +1012,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
         }
       }
     }
+    AF_PS_STAMP(4);  // coarse correlation
     float Syy0;
     {
       float acc = 0.0f;
@@ -1004,6 +1025,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     static_assert(mp == 147, "coarse lag count");
     best_pitch_scan_wave<mp>(S.c.numa, S.c.da, S.c.syy, Syy0, lane, best0, best1);
   }
+  AF_PS_STAMP(5);  // coarse scan
   wave_lds_fence();  // the coarse arrays are dead: the fine stage's take their place
   {
     // fine: 2x decimated, only within +-2 of the two coarse candidates (at most ten lags)
@@ -1031,6 +1053,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
         }
       }
     }
+    AF_PS_STAMP(6);  // fine correlations
     const float Syy0 = 1.0f + wave_dot64(ds, ds, len, lane);
     wave_lds_fence();
     best_pitch_scan_wave<mp>(S.f.numa, S.f.da, S.f.syy, Syy0, lane, best0, best1);
@@ -1046,6 +1069,8 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     pitch_index = kPitchMax - (2 * best0 - offset);
   }
   if (lane == 0) rec->pitch_index = pitch_index;
+  AF_PS_STAMP(7);  // fine scan
+  AF_PS_PRINT;
 }
 
 // ---- pitch, part 2: what looks at the previous frame (wave per stream, frames in order): octave-error removal

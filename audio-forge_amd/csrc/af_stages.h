@@ -36,8 +36,9 @@ struct StageRings {
   double *de_env[3], *de_bb;                     // band envelopes, broadband envelope
   double *de_ct[3], *de_ratio[3], *de_aux[3];    // confidence target, band-to-voice ratio (dB), voice-active flag / band level (dB)
   double *de_tr[3];                              // raw reduction targets (dB)
+  double *de_red[3];                             // smoothed reductions (dB)
   double *de_gdb[3];                             // the dynamic EQs' gains after the 0.001 dB hold
-  float *de_upd;                                 // bit i: band i's coefficients change at this sample
+  float *de_upd[3];                              // 1.0: the band's coefficients change at this sample
   double *de_c[3][5];                            // the coefficients they change to
   float *de_y[3];                                // audio after dynamic EQ 0, 1, 2
   int32_t rows_f32, rows_f64;                    // ring lengths
@@ -88,7 +89,9 @@ enum StageId : int {
   kStDe1a, kStDe1b, kStDe1c,  // serial, one per band: detector high-pass -> low-pass -> envelope (band 0 also the broadband envelope)
   kStDe2,      // levels in dB, voice reference, narrowness, dominance, confidence targets
   kStDe3a, kStDe3b, kStDe3c,  // serial, one per band: confidence, baseline, raw reduction target
-  kStDe4,      // serial: target scaling, reduction smoothing, the 0.001 dB hold on the dynamic EQs' gains, block figure
+  kStDe4s,     // serial: the raw targets scaled to the total budget (in place)
+  kStDe4a, kStDe4b, kStDe4c,  // serial, one per band: reduction smoothing, the 0.001 dB hold on the dynamic EQ's gain
+  kStDe4t,     // serial: total reduction -> the block's figure (feeds no other stage)
   kStDe5,      // the peaking coefficients of every changed gain
   kStDe6a, kStDe6b, kStDe6c,  // serial, cascaded: the three dynamic EQs
   kStCount
@@ -121,6 +124,7 @@ struct DiagArgs {
   uint32_t flags;              // chain flags the pipeline was planned for
   int32_t sidechain, adaptive, auto_makeup;  // compressor switches (they pick code paths)
   int32_t deesser;             // the de-esser stages run ahead of the EQ (which then reads their output ring)
+  int32_t debug_skip;          // timing probes only (AF_STAGE_SKIP=<StageId>): that stage returns at once; results are garbage
 };
 // `kind` (stage_dispatch_kind): 0 = the one-wave roles (serial stages, F4, the EQ), 1 = the wide stages (workgroups of four
 // waves), 2 = the de-esser's serial stages (one wave each, a kernel of their own)

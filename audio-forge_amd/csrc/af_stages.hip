@@ -25,6 +25,7 @@
 // without the suppressor, more than 16 EQ sections, presets that differ in which stages run, the time-major layout.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "af_deesser_math.h"
@@ -1529,31 +1530,122 @@ __device__ __forceinline__ void stage_de3_body(const StageArgs &a, int bx) {
   }
 }
 
-// target scaling, reduction smoothing, the 0.001 dB hold on the dynamic EQs' gains (deesser.rs:518-538), the block's figure
-__device__ __forceinline__ void stage_de4_body(const StageArgs &a, int bx) {
+// ---- deesser.rs:518-538 as three kinds of stage (one wave doing all of it was the pipeline's slowest stage by 15 %):
+// De4s: the targets scaled to the total budget (in place in the target rings); De4a/b/c: one band's reduction smoothing and
+// the 0.001 dB hold on its dynamic EQ's gain; De4t: the total reduction -> the block's figure (feeds no other stage).
+__device__ __forceinline__ void stage_de4s_body(const StageArgs &a, int bx) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  __builtin_amdgcn_s_setprio(3);
+  const int R = a.r.rows_f64;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t q_first = n0 >> 2, q_last = (n_end - 1) >> 2;
+  double *r_tr[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) r_tr[b] = a.r.de_tr[b] + (int64_t)w.g * R * kLanes;
+  const double max_reduction_db = P.deesser.max_reduction_db;
+  struct Slot {
+    Quad<double> t[3];
+  };
+  auto fetch = [&](int64_t q) {
+    const int64_t o = qoff(q, R) + w.lane * kQ;
+    return Slot{{load_quad(r_tr[0] + o), load_quad(r_tr[1] + o), load_quad(r_tr[2] + o)}};
+  };
+  Slot s0 = fetch(q_first), s1 = fetch(q_first + 1);
+  for (int64_t q = q_first; q <= q_last; ++q) {
+    Slot cur = s0;
+    s0 = s1;
+    s1 = fetch(q + 2);
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) {
+      const int64_t na = q * kQ + j;
+      if (na < n0 || na >= n_end) continue;
+      double target_sum = 0.0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) target_sum += cur.t[b].v[j];
+      if (target_sum > max_reduction_db && target_sum > 0.0) {
+        const double scale = max_reduction_db / target_sum;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) cur.t[b].v[j] *= scale;
+        any = true;
+      }
+    }
+    if (any) {  // (a quad whose targets stayed as they were is not written back)
+      const int64_t o = qoff(q, R) + w.lane * kQ;
+#pragma unroll
+      for (int j = 0; j < kQ; ++j)
+        if (q * kQ + j >= n0 && q * kQ + j < n_end) {
+#pragma unroll
+          for (int b = 0; b < 3; ++b) r_tr[b][o + j] = cur.t[b].v[j];
+        }
+    }
+  }
+}
+
+template <int kBand>
+__device__ __forceinline__ void stage_de4b_body(const StageArgs &a, int bx) {
   const Who w = who(a, bx);
   const ChainParams &P = preset(a, w.g);
   const DeEsserParams &D = P.deesser;
   __builtin_amdgcn_s_setprio(3);
   const int64_t n = a.n, n0 = a.n0;
   const int64_t q_first = n0 >> 2, q_last = (n0 + n - 1) >> 2;
-  const int R = a.r.rows_f64, R32 = a.r.rows_f32;
-  const double *r_tr[3];
-  double *r_g[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    r_tr[b] = a.r.de_tr[b] + (int64_t)w.g * R * kLanes;
-    r_g[b] = a.r.de_gdb[b] + (int64_t)w.g * R * kLanes;
+  Ahead<double> in;
+  in.init(a.r.de_tr[kBand], w.g, w.lane, a.r.rows_f64, q_first);
+  Out<double> o_g, o_red;
+  o_g.init(a.r.de_gdb[kBand], w.g, w.lane, a.r.rows_f64);
+  o_red.init(a.r.de_red[kBand], w.g, w.lane, a.r.rows_f64);
+  Out<float> o_upd;
+  o_upd.init(a.r.de_upd[kBand], w.g, w.lane, a.r.rows_f32);
+  double *p = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.sc];
+  double red = p[3 * w.NS], gdb = p[4 * w.NS];
+  const double attack = D.attack_coeff, release = D.release_coeff;
+  int dummy = 0;
+  for_blocks(q_first, q_last, [&](int64_t qb, auto buf_tag) {
+    constexpr int kBuf = decltype(buf_tag)::value;
+    const double(&cur)[kU] = in.template buf<kBuf>();
+    auto step = [&](int u) {
+      red = smooth_value(red, cur[u], attack, release);
+      const double gain = -red;
+      const bool upd = fabs(gdb - gain) > 0.001;  // set_gain_db_immediate (deesser.rs:536-538)
+      gdb = upd ? gain : gdb;
+      o_red.v[u] = red;
+      o_g.v[u] = gdb;
+      o_upd.v[u] = upd ? 1.0f : 0.0f;
+    };
+    run_block<false>(
+        qb, n0, n, 0, dummy, step,
+        [&] {
+          o_red.store_all(qb);
+          o_g.store_all(qb);
+          o_upd.store_all(qb);
+        },
+        [&](int u) {
+          o_red.store_one(qb, u);
+          o_g.store_one(qb, u);
+          o_upd.store_one(qb, u);
+        },
+        [] {});
+    in.template refill<kBuf>(qb);
+  });
+  if (w.valid) {
+    double *q = &a.st64[(int64_t)(kDeBand0 + kBand * kDeBandStride) * w.NS + w.s];
+    q[3 * w.NS] = red;
+    q[4 * w.NS] = gdb;
   }
-  float *r_upd = a.r.de_upd + (int64_t)w.g * R32 * kLanes;
-  double red[3], gdb[3];
+}
+
+__device__ __forceinline__ void stage_de4t_body(const StageArgs &a, int bx) {
+  const Who w = who(a, bx);
+  const ChainParams &P = preset(a, w.g);
+  const int R = a.r.rows_f64;
+  const int64_t n0 = a.n0, n_end = a.n0 + a.n;
+  const int64_t q_first = n0 >> 2, q_last = (n_end - 1) >> 2;
+  const double *r_red[3];
 #pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    const double *p = &a.st64[(int64_t)(kDeBand0 + b * kDeBandStride) * w.NS + w.sc];
-    red[b] = p[3 * w.NS];
-    gdb[b] = p[4 * w.NS];
-  }
-  const double max_reduction_db = D.max_reduction_db, attack = D.attack_coeff, release = D.release_coeff;
+  for (int b = 0; b < 3; ++b) r_red[b] = a.r.de_red[b] + (int64_t)w.g * R * kLanes;
+  const double max_reduction_db = P.deesser.max_reduction_db;
   double current_reduction = a.st64[(int64_t)kDeCurrentReduction * w.NS + w.sc];
   const int cb = P.control_block;
   BlockStats *stats = a.stats;
@@ -1564,47 +1656,21 @@ __device__ __forceinline__ void stage_de4_body(const StageArgs &a, int bx) {
   };
   auto fetch = [&](int64_t q) {
     const int64_t o = qoff(q, R) + w.lane * kQ;
-    return Slot{{load_quad(r_tr[0] + o), load_quad(r_tr[1] + o), load_quad(r_tr[2] + o)}};
+    return Slot{{load_quad(r_red[0] + o), load_quad(r_red[1] + o), load_quad(r_red[2] + o)}};
   };
-  const int64_t n_end = n0 + n;
   Slot s0 = fetch(q_first), s1 = fetch(q_first + 1);
   for (int64_t q = q_first; q <= q_last; ++q) {
     const Slot cur = s0;
     s0 = s1;
     s1 = fetch(q + 2);
-    double og[3][kQ];
-    float ou[kQ];
 #pragma unroll
     for (int j = 0; j < kQ; ++j) {
       const int64_t na = q * kQ + j;
-      ou[j] = 0.0f;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) og[b][j] = 0.0;
       if (na < n0 || na >= n_end) continue;
-      double target[3] = {cur.t[0].v[j], cur.t[1].v[j], cur.t[2].v[j]};
-      double target_sum = 0.0;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) target_sum += target[b];
-      if (target_sum > max_reduction_db && target_sum > 0.0) {
-        const double scale = max_reduction_db / target_sum;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) target[b] *= scale;
-      }
       double total_reduction = 0.0;
-      int upd = 0;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        red[b] = smooth_value(red[b], target[b], attack, release);
-        total_reduction += red[b];
-        const double gain = -red[b];
-        if (fabs(gdb[b] - gain) > 0.001) {  // set_gain_db_immediate (deesser.rs:536-538)
-          gdb[b] = gain;
-          upd |= 1 << b;
-        }
-        og[b][j] = gdb[b];
-      }
+      for (int b = 0; b < 3; ++b) total_reduction += cur.t[b].v[j];
       current_reduction = fmin(total_reduction, max_reduction_db);
-      ou[j] = (float)upd;
       in_block += 1;
       if (in_block == cb || na + 1 == n_end) {  // (wave-uniform) a control block, or the window, ends with this sample
         if (w.valid && stats) stats[blk * w.NS + w.s].deesser_gr_db = (float)current_reduction;
@@ -1612,33 +1678,8 @@ __device__ __forceinline__ void stage_de4_body(const StageArgs &a, int bx) {
         in_block = 0;
       }
     }
-    const int64_t o64 = qoff(q, R) + w.lane * kQ, o32 = qoff(q, R32) + w.lane * kQ;
-    if (q * kQ >= n0 && q * kQ + 3 < n_end) {
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        *reinterpret_cast<double2 *>(r_g[b] + o64) = make_double2(og[b][0], og[b][1]);
-        *reinterpret_cast<double2 *>(r_g[b] + o64 + 2) = make_double2(og[b][2], og[b][3]);
-      }
-      *reinterpret_cast<float4 *>(r_upd + o32) = make_float4(ou[0], ou[1], ou[2], ou[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < kQ; ++j)
-        if (q * kQ + j >= n0 && q * kQ + j < n_end) {
-#pragma unroll
-          for (int b = 0; b < 3; ++b) r_g[b][o64 + j] = og[b][j];
-          r_upd[o32 + j] = ou[j];
-        }
-    }
   }
-  if (w.valid) {
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      double *q = &a.st64[(int64_t)(kDeBand0 + b * kDeBandStride) * w.NS + w.s];
-      q[3 * w.NS] = red[b];
-      q[4 * w.NS] = gdb[b];
-    }
-    a.st64[(int64_t)kDeCurrentReduction * w.NS + w.s] = current_reduction;
-  }
+  if (w.valid) a.st64[(int64_t)kDeCurrentReduction * w.NS + w.s] = current_reduction;
 }
 
 // the peaking coefficients of every gain that changed (Biquad::calculate_coefficients, biquad.rs:109-182)
@@ -1650,23 +1691,24 @@ __device__ __forceinline__ void stage_de5_body(const StageArgs &a, int bx, int b
   const int64_t gb = (int64_t)g * R * kLanes, gb32 = (int64_t)g * R32 * kLanes;
   const int i = threadIdx.x;
   const int64_t q0 = (a.n0 >> 2) + (int64_t)bx * kFfQuads;
-  float upd[kFfQuads];
+  float upd[3][kFfQuads];
   double gd[3][kFfQuads];
 #pragma unroll
   for (int k = 0; k < kFfQuads; ++k) {
-    upd[k] = a.r.de_upd[gb32 + qoff(q0 + k, R32) + i];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) gd[b][k] = a.r.de_gdb[b][gb + qoff(q0 + k, R) + i];
+    for (int b = 0; b < 3; ++b) {
+      upd[b][k] = a.r.de_upd[b][gb32 + qoff(q0 + k, R32) + i];
+      gd[b][k] = a.r.de_gdb[b][gb + qoff(q0 + k, R) + i];
+    }
   }
 #pragma unroll
   for (int k = 0; k < kFfQuads; ++k) {
     const Elem e = ff_elem(a, q0 + k, i, R);
     if (!e.in) continue;
     const int64_t row = gb + e.idx;
-    const int bits = (int)upd[k];
 #pragma unroll
     for (int b = 0; b < 3; ++b)
-      if (bits & (1 << b)) {
+      if (upd[b][k] != 0.0f) {
         const BiquadCoef c = peaking(D.bands[b].dyn_cos_omega, D.bands[b].dyn_alpha, gd[b][k]);
         a.r.de_c[b][0][row] = c.b0;
         a.r.de_c[b][1][row] = c.b1;
@@ -1688,7 +1730,7 @@ __device__ __forceinline__ void stage_de6_body(const StageArgs &a, const ChainPa
   const int64_t n0 = a.n0, n_end = a.n0 + a.n;
   const int64_t q_first = n0 >> 2, q_last = (n_end - 1) >> 2;
   const float *src = (kBand == 0 ? a.r.xi : a.r.de_y[kBand - 1]) + (int64_t)w.g * R32 * kLanes;
-  const float *updr = a.r.de_upd + (int64_t)w.g * R32 * kLanes;
+  const float *updr = a.r.de_upd[kBand] + (int64_t)w.g * R32 * kLanes;
   float *dst = a.r.de_y[kBand] + (int64_t)w.g * R32 * kLanes;
   const double *cr[5];
 #pragma unroll
@@ -1721,7 +1763,7 @@ __device__ __forceinline__ void stage_de6_body(const StageArgs &a, const ChainPa
       const int64_t na = q * kQ + j;
       y[j] = 0.0f;
       if (na < n0 || na >= n_end) continue;
-      if (((int)cur.u.v[j]) & (1 << kBand)) {  // set_coefficients_immediate: new coefficients, a pending crossfade is cancelled
+      if (cur.u.v[j] != 0.0f) {  // set_coefficients_immediate: new coefficients, a pending crossfade is cancelled
         dyn = BiquadCoef{cur.c[0].v[j], cur.c[1].v[j], cur.c[2].v[j], cur.c[3].v[j], cur.c[4].v[j]};
         cancelled = 1.0;
         eq.pz1 = 0.0;
@@ -1782,6 +1824,29 @@ __device__ __forceinline__ StageArgs role_args(const DiagArgs &d, const DiagRole
   return a;
 }
 
+__device__ __forceinline__ bool deesser_serial_role(const DiagArgs &d, const DiagRole &role, const StageArgs &a, int bx) {
+  const ChainParams &PW = d.params_eq[role.win.eq_slot];  // the window's own parameter block
+  switch (role.stage) {
+    case kStDe1a: stage_de1_body<0>(a, PW, bx); return true;
+    case kStDe1b: stage_de1_body<1>(a, PW, bx); return true;
+    case kStDe1c: stage_de1_body<2>(a, PW, bx); return true;
+    case kStDe3a: stage_de3_body<0>(a, bx); return true;
+    case kStDe3b: stage_de3_body<1>(a, bx); return true;
+    case kStDe3c: stage_de3_body<2>(a, bx); return true;
+    case kStDe4s: stage_de4s_body(a, bx); return true;
+    case kStDe4a: stage_de4b_body<0>(a, bx); return true;
+    case kStDe4b: stage_de4b_body<1>(a, bx); return true;
+    case kStDe4c: stage_de4b_body<2>(a, bx); return true;
+    case kStDe4t: stage_de4t_body(a, bx); return true;
+    case kStDe6a: stage_de6_body<0>(a, PW, bx); return true;
+    case kStDe6b: stage_de6_body<1>(a, PW, bx); return true;
+    case kStDe6c: stage_de6_body<2>(a, PW, bx); return true;
+    default: return false;
+  }
+}
+
+// kDe: the de-esser's serial stages are roles of this dispatch too (a build of its own: the plain chain's keeps its registers)
+template <bool kDe>
 __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   const RolePick pk = pick_role(d);
   const DiagRole &role = d.roles[pk.r];
@@ -1789,6 +1854,11 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   const int bx = pk.bx, by = pk.by;
   const bool comp = (d.flags & kFlagCompressor) != 0, lim = (d.flags & kFlagLimiter) != 0;
   const float *lim_in = comp ? a.r.xc : a.r.xe;
+  if (role.stage == d.debug_skip) return;
+  if (kDe && role.stage >= kStDe0) {
+    deesser_serial_role(d, role, a, bx);
+    return;
+  }
   switch (role.stage) {
     case kStEq: {
       EqSystolicArgs ea{d.params_eq + role.win.eq_slot, a.group_preset, a.st64, a.in, nullptr, a.r.xe, d.deesser ? nullptr : a.r.xi, nullptr,
@@ -1830,26 +1900,13 @@ __global__ __launch_bounds__(64) void stage_diag_serial_kernel(DiagArgs d) {
   }
 }
 
-// the de-esser's serial stages: a dispatch of their own (inside the kernel above their registers would be every role's)
+// the de-esser's serial stages as a kernel of their own (AF_DEESSER_DISPATCH=1: a third dispatch per step; the default runs them
+// as roles of the serial dispatch above, side by side with the chain's serial stages)
 __global__ __launch_bounds__(64) void stage_diag_deesser_kernel(DiagArgs d) {
   const RolePick pk = pick_role(d);
   const DiagRole &role = d.roles[pk.r];
   const StageArgs a = role_args(d, role);
-  const int bx = pk.bx;
-  const ChainParams &PW = d.params_eq[role.win.eq_slot];  // the window's own parameter block
-  switch (role.stage) {
-    case kStDe1a: stage_de1_body<0>(a, PW, bx); break;
-    case kStDe1b: stage_de1_body<1>(a, PW, bx); break;
-    case kStDe1c: stage_de1_body<2>(a, PW, bx); break;
-    case kStDe3a: stage_de3_body<0>(a, bx); break;
-    case kStDe3b: stage_de3_body<1>(a, bx); break;
-    case kStDe3c: stage_de3_body<2>(a, bx); break;
-    case kStDe4: stage_de4_body(a, bx); break;
-    case kStDe6a: stage_de6_body<0>(a, PW, bx); break;
-    case kStDe6b: stage_de6_body<1>(a, PW, bx); break;
-    case kStDe6c: stage_de6_body<2>(a, PW, bx); break;
-    default: break;
-  }
+  deesser_serial_role(d, role, a, pk.bx);
 }
 
 __global__ __launch_bounds__(256) void stage_diag_wide_kernel(DiagArgs d) {
@@ -1893,9 +1950,14 @@ unsigned stage_role_blocks(int stage, int64_t n0, int64_t n, int32_t n_streams, 
 }
 
 int stage_dispatch_kind(int stage) {
+  static const bool own_dispatch = [] {  // AF_DEESSER_DISPATCH=1: the de-esser's serial stages as a third dispatch per step
+    const char *env = std::getenv("AF_DEESSER_DISPATCH");
+    return env && std::atoi(env) != 0;
+  }();
   switch (stage) {
     case kStF1: case kStF2: case kStFR: case kStF3: case kStF3a: case kStF5: case kStF6: case kStDe0: case kStDe2: case kStDe5: return 1;
-    case kStDe1a: case kStDe1b: case kStDe1c: case kStDe3a: case kStDe3b: case kStDe3c: case kStDe4: case kStDe6a: case kStDe6b: case kStDe6c: return 2;
+    case kStDe1a: case kStDe1b: case kStDe1c: case kStDe3a: case kStDe3b: case kStDe3c: case kStDe4s: case kStDe4a: case kStDe4b: case kStDe4c: case kStDe4t: case kStDe6a: case kStDe6b: case kStDe6c:
+      return own_dispatch ? 2 : 0;
     default: return 0;
   }
 }
@@ -1904,7 +1966,8 @@ hipError_t launch_stage_diag(const DiagArgs &d, unsigned total_blocks, int kind,
   if (total_blocks == 0) return hipSuccess;
   if (kind == 1) hipLaunchKernelGGL(stage_diag_wide_kernel, dim3(total_blocks), dim3(256), 0, stream, d);
   else if (kind == 2) hipLaunchKernelGGL(stage_diag_deesser_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
-  else hipLaunchKernelGGL(stage_diag_serial_kernel, dim3(total_blocks), dim3(64), 0, stream, d);
+  else if (d.deesser) hipLaunchKernelGGL(stage_diag_serial_kernel<true>, dim3(total_blocks), dim3(64), 0, stream, d);
+  else hipLaunchKernelGGL(stage_diag_serial_kernel<false>, dim3(total_blocks), dim3(64), 0, stream, d);
   return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ def synth_batch(n_streams: int, n_blocks: int, first_stream: int, device: torch.
 CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: max shader clock (the issue roof below is priced at it)
 
 
-def profile_counters(full: bool, streams: int, seconds: float, auto_makeup: bool = False):
+def profile_counters(full: bool, streams: int, seconds: float, auto_makeup: bool = False, deesser: bool = False):
     """Counter figures of this workload from the committed rocprofv3 --pmc passes (profiles/r*_*counters*.json, written by
     tools/step_counters.py from separate counter runs of this same command; counters cannot be read from inside a timed
     run).  The newest round's file taken at exactly this shape is used; it carries the commit it was taken at."""
@@ -93,7 +93,8 @@ def profile_counters(full: bool, streams: int, seconds: float, auto_makeup: bool
             continue
         shape = prof.get("shape") or {}
         if (shape.get("streams") == streams and shape.get("seconds") == seconds and shape.get("chain") == ("full" if full else "dynamics")
-                and bool(shape.get("auto_makeup", False)) == auto_makeup and "kernels" in prof):
+                and bool(shape.get("auto_makeup", False)) == auto_makeup and bool(shape.get("deesser", False)) == deesser
+                and "kernels" in prof):
             prof["_file"] = f"profiles/{path.name}"
             best = prof  # (sorted by name: the highest round wins)
     return best
@@ -318,6 +319,9 @@ def main() -> None:
     ap.add_argument("--auto-makeup", action="store_true",
                     help="compressor auto-makeup on (north_star's chain as literally named: per-block activity -> momentary "
                          "loudness -> makeup, compressor.rs:598-653); target -16 LUFS")
+    ap.add_argument("--deesser", action="store_true",
+                    help="three-band de-esser ahead of the EQ (deesser.rs:405-547; the golden KAT's settings: auto amount 0.85, "
+                         "max reduction 10 dB) -- SURVEY 8(f) row 1, not part of BASELINE's configs")
     ap.add_argument("--force-distributed", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the barrier and both metric all-reduces on device tensors "
                          "even with one rank (RANK=0 WORLD_SIZE=1): executes the collective path on a one-GPU box")
@@ -386,6 +390,8 @@ def main() -> None:
     chain_settings = dict(CHAIN_SETTINGS)
     if args.auto_makeup:
         chain_settings.update(compressor_auto_makeup_enabled=True, compressor_target_lufs=-16.0)
+    if args.deesser:
+        chain_settings.update(deesser_enabled=True, deesser_auto_enabled=True, deesser_auto_amount=0.85, deesser_max_reduction_db=10.0)
     core.configure_auto_eq_chain(engine, float(SAMPLE_RATE), BANDS, chain_settings)
     if not args.variant:
         engine.set_kernel(args.kernel)
@@ -438,7 +444,8 @@ def main() -> None:
     ring = args.variant[5:] if args.variant.startswith("ring-") else "16x4"
     quad = args.variant[5:] if args.variant.startswith("quad-") else "12"
     kernel_name = {1: "chain_lane_kernel", 2: f"chain_ring_kernel<{ring}>", 3: f"chain_quad_kernel<{quad}>",
-                   4: "stage_diag_serial_kernel (the serial stages of one launch step of the stage pipeline)"}.get(used, "?")
+                   4: "stage_diag_serial_kernel (the serial stages of one launch step of the stage pipeline)",
+                   5: "chain_comp_roles_kernel + chain_lim_roles_kernel (role pipeline)"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on the stream it runs on)
         # (with the suppressor on the chain runs once per window, so a step holds several launches)
@@ -458,9 +465,9 @@ def main() -> None:
                                   "dependent-instruction latency of one wave per recurrence (~8 cycles per vector instruction, "
                                   "tools/probe/valu_latency.hip): a step lasts as long as its longest stage, the EQ"),
         }
-        prof = profile_counters(full, streams, args.seconds, args.auto_makeup)
+        prof = profile_counters(full, streams, args.seconds, args.auto_makeup, args.deesser)
         if prof is not None:
-            row = next((v for k, v in prof["kernels"].items() if kernel_name.split("<")[0] in k), None)
+            row = next((v for k, v in prof["kernels"].items() if kernel_name.split("<")[0].split(" ")[0] in k), None)
             if row is not None:
                 per_launch = row["launches_per_step"]
                 roofline["traffic"] = (row["fetch_bytes"] + row["write_bytes"]) / per_launch  # HBM bytes per launch (PMC)
@@ -508,7 +515,7 @@ def main() -> None:
                              f"limiter + 4x true-peak limiter/detector, no suppressor (BASELINE configs[1] chain)"),
                 "streams_per_gpu": streams, "seconds": args.seconds, "control_block": 960, "layout": "stream-major",
                 "kernel": kernel_name, "sharding": f"streams x{world}, no data-path collective",
-                "auto_makeup": bool(args.auto_makeup),
+                "auto_makeup": bool(args.auto_makeup), "deesser": bool(args.deesser),
             },
             "collective": collective,
             "roofline": roofline,

@@ -67,14 +67,14 @@ for i, a in enumerate(args):
 out = {
     "_how": "tools/step_counters.sh: five separate `rocprofv3 --pmc <group> --kernel-trace` runs of `python bench.py --steps 1 --warmup 1 "
             "--no-cpu-baseline` (FETCH_SIZE | WRITE_SIZE | SQ instruction counts | SQ activity | matrix-core counters), per-kernel totals divided by the 2 steps of a run",
-    "commit": commit or None, "shape": {"streams": streams, "seconds": seconds, "chain": chain, "auto_makeup": "--auto-makeup" in args},
+    "commit": commit or None, "shape": {"streams": streams, "seconds": seconds, "chain": chain, "auto_makeup": "--auto-makeup" in args, "deesser": "--deesser" in args},
     "kernels": kernels,
 }
 import os
 
 tag = os.environ.get("ROUND", "r03")
-suffix = "" if (chain, streams, "--auto-makeup" in args) == ("full", 4096, False) else (
-    f"_{chain}_{streams}" + ("_automakeup" if "--auto-makeup" in args else ""))
+suffix = "" if (chain, streams, "--auto-makeup" in args, "--deesser" in args) == ("full", 4096, False, False) else (
+    f"_{chain}_{streams}" + ("_automakeup" if "--auto-makeup" in args else "") + ("_deesser" if "--deesser" in args else ""))
 dest = ROOT / "gpurun_out" / f"{tag}_step_counters{suffix}.json"
 dest.write_text(json.dumps(out, indent=1, sort_keys=True))
 total = sum(k["fetch_bytes"] + k["write_bytes"] for k in kernels.values())
