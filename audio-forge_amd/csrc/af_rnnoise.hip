@@ -854,7 +854,7 @@ constexpr int kPsFrames = 4;                                   // frames (waves)
 constexpr int kPsRaw = kPitchBuf + (kPsFrames - 1) * kRnnFrame;  // samples of the shared span: 3168
 struct PsScan {  // a wave's scan arrays: the coarse stage's (d4, numa, da, syy over 147 lags), then the fine stage's (294 lags)
   union {
-    struct { float d4[kPitchBuf / 4]; float numa[152], da[152], syy[152]; } c;
+    struct { float d4[kPitchBuf / 4]; float numa[152], da[152], syy[152]; float x4p[256]; } c;  // x4p: x[j] at j + (j >> 4)
     struct { float xc[304], numa[304], da[304], syy[304]; } f;
   };
 };
@@ -983,20 +983,27 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   {
     // coarse: 4x decimated, 147 lags x 240 products on the matrix cores (see the one-wave kernel above)
     constexpr int len = kRnnWindow >> 2, mp = (kPitchMax - 3 * kPitchMin) >> 2;
-    for (int i = lane; i < kPitchBuf / 4; i += 64) S.c.d4[i] = ds[2 * i];
+    for (int i = lane; i < kPitchBuf / 4; i += 64) {
+      const float v = ds[2 * i];
+      S.c.d4[i] = v;
+      // the B operand reads x[4 s + k - 16 c]: sixteen columns 16 apart -- two banks for a whole half-wave in the plain layout
+      // (most of this kernel's 0.52 conflict / LDS-active ratio); one pad word per sixteen makes the column stride 17
+      const int j = i - (kPitchMax >> 2);
+      if (j >= 0 && j < len) S.c.x4p[j + (j >> 4)] = v;
+    }
     wave_lds_fence();
     {
       typedef float v4f_ps __attribute__((ext_vector_type(4)));
       v4f_ps acc = {0.0f, 0.0f, 0.0f, 0.0f};
       const int col = lane & 15, kq = lane >> 4;
       const float *ap = S.c.d4 + kq + col;          // y[4 s + k + i]
-      const float *x4 = S.c.d4 + (kPitchMax >> 2);  // x[j] = x_lp[2 j]
+      const float *x4 = S.c.x4p;                    // x[j] = x_lp[2 j] at j + (j >> 4)
       int xi = kq - 16 * col;                       // 4 s + k - 16 c at s = 0
 #pragma unroll 4
       for (int st = 0; st < 96; ++st) {
         const float av = ap[4 * st];
         const bool in = (unsigned)xi < (unsigned)len;
-        const float bv = in ? x4[in ? xi : 0] : 0.0f;
+        const float bv = in ? x4[in ? xi + (xi >> 4) : 0] : 0.0f;
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         xi += 4;
       }
@@ -1395,7 +1402,13 @@ __device__ __forceinline__ float sigmoid_approx(const float *table, float x) { r
 //   * the next frame's features are fetched while the current frame computes.
 // Arithmetic per (stream, unit) is the same k-ordered fmaf chain from the bias as before: results are unchanged
 // bit for bit (tools/ab_suppressor.py).
-constexpr int kR1 = 140, kR2 = 212;
+// Row strides of the two activation rows per stream.  A matrix step reads A[stream = lane & 15][k0 + (lane >> 4)]: within a
+// half-wave sixteen streams x two k.  With the rows exactly as long as their contents (140 / 212 floats: 12 and 20 mod 32) streams
+// c and c + 8 met in the same bank on EVERY read (LDS conflict cycles 1.05 x the LDS-active cycles in round 2's counters); a stride
+// of 2 mod 32 spreads a half-wave's 32 reads over the 32 banks.  (The tails are never read: K_PAD ends inside the contents.)
+constexpr int kR1Len = 140, kR2Len = 212;
+constexpr int kR1 = 162, kR2 = 226;
+static_assert(kR1 >= kR1Len && kR2 >= kR2Len && kR1 % 32 == 2 && kR2 % 32 == 2, "activation row strides");
 constexpr int kR1Vad = 24, kR1Feat = 48, kR1Noise = 90;   // r1 = [dense 24 | vad 24 | features 42 | noise 48 | 0 0]
 constexpr int kR2Noise = 24, kR2Feat = 72, kR2Den = 114;  // r2 = [vad 24 | noise 48 | features 42 | denoise 96 | 0 0]
 constexpr int kRnnBiasTiles = 37;  // dense 2 | vad z r h 2 each | noise z r h 3 each | denoise z r h 6 each | out 2
