@@ -416,11 +416,6 @@ int ensure_started(af_engine *e) {
           return fail(AF_ERR_INVALID_ARGUMENT, "every preset of an engine must use the same control block");
         if (ps.proto.sample_rate != e->proto.sample_rate) return fail(AF_ERR_INVALID_ARGUMENT, "presets must share the sample rate");
       }
-      for (int k = 0; k <= (int)e->extra_presets.size(); ++k) {
-        const af::ChainParams &hp = preset_params(e, k);
-        if ((hp.flags & af::kFlagDeesser) || ((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled))
-          return fail(AF_ERR_UNSUPPORTED, "the de-esser and auto-makeup passes are built for single-preset engines only");
-      }
       if (e->kernel != AF_KERNEL_AUTO && e->kernel != AF_KERNEL_PHASED && e->kernel != AF_KERNEL_STAGED)
         return fail(AF_ERR_UNSUPPORTED, "multi-preset engines run the token-ring kernel or the stage pipeline");
       const size_t n_groups = (size_t)(e->n_streams + 63) / 64;
@@ -509,6 +504,13 @@ int launch_chain_multi(af_engine *e, uint32_t strip, uint32_t add, const float *
                        int64_t stream_stride, int32_t layout, int64_t samples_before, af::BlockStats *stats, hipStream_t stream,
                        bool stats_cleared) {
   const int n_presets = 1 + (int)e->extra_presets.size();
+  for (int k = 0; k < n_presets; ++k) {
+    // (the stage pipeline runs both for several presets, when the presets agree on which stages there are: stage_pipe_serves)
+    const af::ChainParams &hp = preset_params(e, k);
+    if ((hp.flags & af::kFlagDeesser) || ((hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled))
+      return fail(AF_ERR_UNSUPPORTED, "several presets with the de-esser or auto-makeup run on the stage pipeline only, and there every "
+                                      "preset must enable the same stages (de-esser ahead of the EQ, compressor, auto-makeup, limiter)");
+  }
   std::vector<af::ChainParams> runs((size_t)n_presets);
   size_t dyn = 0;  // every workgroup lays out its own preset: the launch needs the largest of the layouts
   for (int k = 0; k < n_presets; ++k) {
@@ -847,7 +849,7 @@ bool stage_pipe_serves(af_engine *e, const af::ChainParams &run, int32_t layout)
     // there are and which code paths they take (what differs freely: every coefficient, the EQ, the limiter's lookahead)
     af::ChainParams other = preset_params(e, k);
     other.flags &= ~strip;
-    const uint32_t shape = af::kFlagCompressor | af::kFlagLimiter;
+    const uint32_t shape = af::kFlagCompressor | af::kFlagLimiter | af::kFlagDeesser;
     if (!stage_pipe_serves_one(other) || (other.flags & shape) != (run.flags & shape) ||
         other.comp.sidechain_highpass_enabled != run.comp.sidechain_highpass_enabled ||
         other.comp.adaptive_release != run.comp.adaptive_release || other.comp.auto_makeup_enabled != run.comp.auto_makeup_enabled ||
@@ -1507,7 +1509,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       return fail(AF_ERR_UNSUPPORTED, "the stage pipeline does not build this configuration (EQ-before-de-esser order, front end without the "
                                       "suppressor, more than 16 EQ sections, presets that differ in which stages run, time-major audio)");
     // (with the de-esser at any batch: its lane-per-stream form takes 417 ms per 2 s of audio whatever the batch)
-    const bool deesser_staged = (probe.flags & af::kFlagDeesser) != 0;
+    // (and several presets with auto-makeup: the token-ring kernel's pre-pass pair is a single-preset build)
+    const bool deesser_staged = (probe.flags & af::kFlagDeesser) != 0 ||
+                                (!e->extra_presets.empty() && (probe.flags & af::kFlagCompressor) && probe.comp.auto_makeup_enabled);
     e->pipe.active = serves && (e->kernel == AF_KERNEL_STAGED || (e->kernel == AF_KERNEL_AUTO && env_staged != 0 &&
                                  (deesser_staged || e->n_streams <= (e->supp.enabled ? kStagedAutoMaxStreamsBehindSuppressor : kStagedAutoMaxStreams))) ||
                                 (e->kernel == AF_KERNEL_AUTO && env_staged > 0));

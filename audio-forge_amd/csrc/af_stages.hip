@@ -1825,7 +1825,8 @@ __device__ __forceinline__ StageArgs role_args(const DiagArgs &d, const DiagRole
 }
 
 __device__ __forceinline__ bool deesser_serial_role(const DiagArgs &d, const DiagRole &role, const StageArgs &a, int bx) {
-  const ChainParams &PW = d.params_eq[role.win.eq_slot];  // the window's own parameter block
+  // the window's own parameter block (of this group's preset)
+  const ChainParams &PW = d.params_eq[role.win.eq_slot + (a.group_preset ? a.group_preset[bx] : 0)];
   switch (role.stage) {
     case kStDe1a: stage_de1_body<0>(a, PW, bx); return true;
     case kStDe1b: stage_de1_body<1>(a, PW, bx); return true;

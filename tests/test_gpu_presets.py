@@ -102,7 +102,42 @@ def test_preset_argument_contract(mi):
     with pytest.raises(ValueError, match="does not exist"):
         core._lib.check(eng._lib.af_engine_assign_presets(eng._h, gp.ctypes.data_as(C.POINTER(C.c_int32)), 3))
     eng.select_preset(1)
-    eng.set_deesser_enabled(1)  # a preset with the de-esser: refused at the first process call
-    with pytest.raises(NotImplementedError, match="single-preset"):
+    eng.set_deesser_enabled(1)  # ONE preset with the de-esser (the others without): no kernel runs groups with different stages
+    with pytest.raises(NotImplementedError, match="every preset must enable the same stages"):
         eng.process(np.zeros((130, 960), dtype=np.float32))
     eng.close()
+
+
+@pytest.mark.parametrize("deesser", [False, True], ids=["automakeup", "deesser+automakeup"])
+def test_presets_with_auto_makeup_and_the_deesser(mi, oracle, deesser):
+    """Three presets that all run the compressor's auto-makeup (and, second case, the de-esser ahead of the EQ), different in
+    every coefficient: the stage pipeline runs them as one batch (each 64-stream group reads its own parameter block, per
+    window for the de-esser's crossfade bookkeeping).  Equal to per-stream single-preset runs of the oracle."""
+    audio = S.batch_signal(200, 120)  # 1.2 s: the makeup gain has left its initial value
+    audio[:, 20_000:30_000] *= 3.0
+    presets = []
+    for k, (bands, settings) in enumerate(_presets()):
+        st = dict(settings, compressor_enabled=True, compressor_auto_makeup_enabled=True, compressor_target_lufs=-18.0 - 2.0 * k,
+                  compressor_threshold_db=-30.0 + 3.0 * k, compressor_ratio=3.0 + k, compressor_adaptive_release=True,
+                  compressor_base_release_ms=120.0 + 40.0 * k)  # (which stages run must agree: adaptive release on all three)
+        if deesser:
+            st.update(deesser_enabled=True, deesser_auto_enabled=bool(k != 1), deesser_auto_amount=0.4 + 0.2 * k,
+                      deesser_threshold_db=-42.0 + 2.0 * k, deesser_ratio=5.0, deesser_low_cut_hz=3500.0 + 500.0 * k,
+                      deesser_high_cut_hz=9000.0 + 800.0 * k, deesser_max_reduction_db=6.0 + 2.0 * k)
+        presets.append((bands, st))
+    which = [(5 * i + i // 7) % 3 for i in range(audio.shape[0])]
+    out, results = mi.simulate_auto_eq_chain_batch(audio, 48_000.0, [presets[k][0] for k in which], [presets[k][1] for k in which])
+    checked = {0: 0, 1: 0, 2: 0}
+    worst = 0.0
+    for s in list(range(0, 200, 17)) + [63, 64, 127, 128, 191, 192, 199]:
+        k = which[s]
+        bands, settings = presets[k]
+        want = oracle.simulate_auto_eq_chain(audio[s], 48_000, bands, dict(settings, return_output_audio=True))
+        ref = np.asarray(want["output_audio"], dtype=np.float64)
+        err = float(np.max(np.abs(out[s].astype(np.float64) - ref)))
+        worst = max(worst, err)
+        assert err <= 2e-7, (s, k, err)
+        assert results[s]["processed_samples"] == want["processed_samples"]
+        checked[k] += 1
+    assert all(v >= 3 for v in checked.values())
+    assert float(np.max(np.abs(out))) > 0.05  # (something came out)
