@@ -25,6 +25,7 @@ size_t ring_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool cross
 hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int variant,
                              bool auto_makeup, hipStream_t stream);
 hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream);
+hipError_t launch_chain_publish_ready(int64_t *ready, int64_t samples, hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
                              hipStream_t stream);
 size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
@@ -162,6 +163,7 @@ struct af_engine {
   double vad_reliability = 0.0, noise_floor_db = 0.0, live_noise_reliability = 0.0;
   bool has_evidence = false;
   int32_t *d_status = nullptr;
+  int64_t *d_ready = nullptr;                // samples of the running call the suppressor's side has finished (LaunchArgs::ready)
   int64_t stats_capacity = 0;  // rows
   float *d_io = nullptr;       // staging for the host entry point
   int64_t io_capacity = 0;     // floats
@@ -569,10 +571,14 @@ int engine_event(af_engine *e, hipEvent_t *out_ev);
 int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_modified, const float *in, float *out,
                          int64_t n_samples, int64_t stream_stride, int32_t layout, int64_t samples_before,
                          af::BlockStats *stats, const double *vad, hipStream_t stream, hipStream_t /*caller*/,
-                         bool stats_cleared = false, const double *pre_power = nullptr) {
+                         bool stats_cleared = false, const double *pre_power = nullptr, const int64_t *ready = nullptr) {
   // `stats_cleared`: the rows were zeroed (and partly filled) by an earlier kernel of this window: do not clear them again
   // `pre_power`: [block][stream] compressor-input block powers of this segment, left by the systolic EQ kernel that ran as
   // the window's pre-pass: an auto-makeup segment is then ONE launch
+  // `ready`: the segment is a whole call whose input arrives window by window (LaunchArgs::ready); only the plain one-launch form
+  // of the token-ring kernel follows such a counter -- the caller has checked that this is what the configuration takes
+  if (ready && (!e->extra_presets.empty() || e->kernel == AF_KERNEL_ROLES || roles_mode() != 0))
+    return fail(AF_ERR_BACKEND, "internal: only the plain token-ring launch follows a ready counter");
   if (!e->extra_presets.empty())
     return launch_chain_multi(e, e->host_params.flags & ~run_in.flags, run_in.flags & af::kFlagInputDone, in, out, n_samples,
                               stream_stride, layout, samples_before, stats, stream, stats_cleared);
@@ -789,6 +795,8 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
         a.pre_power = pre_power;
         a.vad_prob = vad;
       }
+      a.ready = ready;
+      ready = nullptr;  // (taken)
       AF_HIP(af::launch_chain_ring(a, run.n_eq_sections, run.lim.lookahead_samples, any_xf, e->ring_variant, auto_makeup, stream));
       e->last_launches += 1;
     }
@@ -806,6 +814,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     }
     e->last_launches += 1;
   }
+  if (ready) return fail(AF_ERR_BACKEND, "internal: a launch that follows a ready counter took a path that does not read it");
   if (input_rows || deesser) {
     AF_HIP(af::launch_merge_side_stats(stats, input_rows, deesser ? e->d_stats_de : nullptr, rows, stream));
     e->last_launches += 1;
@@ -1183,6 +1192,7 @@ void af_engine_destroy(af_engine *e) {
     (void)hipFree(e->d_stats_de);
     (void)hipFree(e->d_vad);
     (void)hipFree(e->d_status);
+    (void)hipFree(e->d_ready);
     (void)hipFree(e->d_io);
     (void)hipFree(e->d_pending);
     (void)hipFree(e->d_group_preset);
@@ -1678,18 +1688,39 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       return !env || std::atoi(env) != 0;
     }();
     std::vector<int64_t> up;
-    for (int64_t n = ((4 + unit - 1) / unit) * unit; n < window; n *= 2) up.push_back(n);
+    static const std::vector<int64_t> up_env = [] {  // AF_SUPP_RAMP_LIST=4,4,8,8,16: the opening windows, in frames (tuning runs)
+      std::vector<int64_t> v;
+      if (const char *env = std::getenv("AF_SUPP_RAMP_LIST"))
+        for (const char *p = env; *p;) {
+          char *end = nullptr;
+          const long n = std::strtol(p, &end, 10);
+          if (end == p) break;
+          if (n > 0) v.push_back(n);
+          p = *end ? end + 1 : end;
+        }
+      return v;
+    }();
+    static const bool ramp_down = [] {  // AF_SUPP_RAMP_END=0: no mirror image at the end of the call
+      const char *env = std::getenv("AF_SUPP_RAMP_END");
+      return !env || std::atoi(env) != 0;
+    }();
+    if (!up_env.empty()) {
+      for (int64_t n : up_env) up.push_back(std::min<int64_t>(window, ((n + unit - 1) / unit) * unit));
+    } else {
+      for (int64_t n = ((4 + unit - 1) / unit) * unit; n < window; n *= 2) up.push_back(n);
+    }
     int64_t up_total = 0;
     for (int64_t n : up) up_total += n;
     if (ramp && !up.empty() && aligned >= 2 * up_total + 2 * window) {
       int64_t f = 0;
       for (int64_t n : up) { win_f0.push_back(f); win_nf.push_back(n); f += n; }
-      const int64_t body_end = aligned - up_total;
+      const int64_t body_end = ramp_down ? aligned - up_total : aligned;
       while (f < body_end) {
         const int64_t n = std::min<int64_t>(window, body_end - f);
         win_f0.push_back(f); win_nf.push_back(n); f += n;
       }
-      for (auto it = up.rbegin(); it != up.rend(); ++it) { win_f0.push_back(f); win_nf.push_back(*it); f += *it; }
+      if (ramp_down)
+        for (auto it = up.rbegin(); it != up.rend(); ++it) { win_f0.push_back(f); win_nf.push_back(*it); f += *it; }
     } else {
       for (int64_t f = 0; f < aligned; f += window) { win_f0.push_back(f); win_nf.push_back(std::min<int64_t>(window, aligned - f)); }
     }
@@ -1753,8 +1784,15 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         if (lim_cus < 0 || chain_cus + lim_cus + 32 > total_cus) lim_cus = 0;
       }
       std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u), lim_mask(total_cus / 32, 0u);
-      for (int bit = 0; bit < total_cus; ++bit)
-        (bit < chain_cus ? chain_mask : (bit < chain_cus + lim_cus ? lim_mask : rest_mask))[bit >> 5] |= 1u << (bit & 31);
+      // AF_CU_PATTERN (placement probe): 0 = the chain takes mask bits 0.. (CU indices 0.. of every XCD); 1 = every other CU
+      // index (bit / 8 even); 2 = the highest bits
+      static const int pattern = [] { const char *v = std::getenv("AF_CU_PATTERN"); return v ? std::atoi(v) : 0; }();
+      for (int bit = 0; bit < total_cus; ++bit) {
+        int rank = bit;  // the chain takes ranks 0 .. chain_cus-1
+        if (pattern == 1) rank = ((bit / 8) % 2 == 0) ? (bit / 16) * 8 + bit % 8 : total_cus / 2 + (bit / 16) * 8 + bit % 8;
+        else if (pattern == 2) rank = total_cus - 1 - bit;
+        (rank < chain_cus ? chain_mask : (rank < chain_cus + lim_cus ? lim_mask : rest_mask))[bit >> 5] |= 1u << (bit & 31);
+      }
       hipError_t err = hipExtStreamCreateWithCUMask(&e->aux_stream, (uint32_t)chain_mask.size(), chain_mask.data());
       if (err == hipSuccess && lim_cus > 0) err = hipExtStreamCreateWithCUMask(&e->lim_stream, (uint32_t)lim_mask.size(), lim_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
@@ -1802,6 +1840,36 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->block_power_capacity = cap / (int64_t)sizeof(double);
   }
   auto next_event = [&](hipEvent_t *out_ev) -> int { return engine_event(e, out_ev); };
+  // The call's statistics rows are cleared ONCE, here (their fields are written by the kernels that own them).  Round 2 cleared
+  // every window's rows in front of its EQ launch: a fill kernel on the suppressor's crowded CUs, 0.05-0.45 ms between the
+  // window's overlap-add and its EQ -- on the path the first chain launches wait for.
+  static const bool clear_per_window = [] {  // AF_STATS_CLEAR=window: round 2's per-window fills (A/B runs)
+    const char *env = std::getenv("AF_STATS_CLEAR");
+    return env && std::strcmp(env, "window") == 0;
+  }();
+  if (!clear_per_window) AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
+  // ---- ONE chain launch per call (round 3).  With the chain's CUs its own, the EQ on the suppressor's side and nothing that
+  // changes the parameter block between windows, the token-ring kernel is launched once, for the whole call, before the first
+  // window: a chunk waits until the counter `d_ready` covers its samples, and every window's EQ launch is followed by a
+  // one-thread kernel that publishes the new count.  What that removes from the chain's stream: 53 dispatches and their
+  // cross-stream dependencies (~0.1 ms each while six other queues are busy: the trace of tools/step_timeline.py), the
+  // state planes' load and write-back per window, and the fill / drain of the 16-wave pipeline per launch.
+  // AF_CHAIN_PERSISTENT=0 restores one launch per window (A/B runs).
+  static const bool persistent_env = [] {
+    const char *env = std::getenv("AF_CHAIN_PERSISTENT");
+    return !env || std::atoi(env) != 0;
+  }();
+  bool persistent = persistent_env && eq_offload && !clear_per_window && e->partition_chain_cus > 0 && !e->pipe.active &&
+                    !std::getenv("AF_DIAG_SKIP_CHAIN") && e->extra_presets.empty() && roles_mode() == 0 &&
+                    (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) && layout == AF_LAYOUT_STREAM_MAJOR &&
+                    !(run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass)) && run.n_eq_sections <= 16 &&
+                    af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, false) <= af::kMaxLdsBytes &&
+                    (!auto_makeup_call || e->d_block_power != nullptr) && win_f0.size() >= 2;
+  for (int j = 0; j < run.n_eq_sections && persistent; ++j) persistent = run.eq[j].xf_remaining == 0;
+  if (persistent) {
+    if (!e->d_ready) AF_HIP(hipMalloc(&e->d_ready, sizeof(int64_t)));
+    AF_HIP(hipMemsetAsync(e->d_ready, 0, sizeof(int64_t), stream));
+  }
   {  // the side streams start after whatever the caller queued before this call
     hipEvent_t ev;
     if (int rc = next_event(&ev)) return rc;
@@ -1896,6 +1964,16 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));
     return AF_OK;
   };
+  if (persistent) {  // the call's one chain launch: resident on the chain's CUs from here on, following `d_ready`
+    af::ChainParams run_p = run;
+    run_p.flags = (run_p.flags & ~af::kFlagEq) | af::kFlagInputDone;  // (what every window's launch was given)
+    const int64_t total = frames * af::kRnnFrame;
+    if (int rc = launch_chain_segment(e, run_p, run_modified, out, out, total, stream_stride, layout, e->samples_processed, e->d_stats,
+                                      e->has_evidence ? e->d_vad : nullptr, e->aux_stream, stream, /*stats_cleared=*/true,
+                                      auto_makeup_call ? e->d_block_power : nullptr, e->d_ready))
+      return rc;
+    eq_needs_chain_done = false;  // (an event behind THIS launch would make the first EQ wait for the launch that waits for it)
+  }
   for (int64_t w = 0; w < std::min<int64_t>(pre_ahead, n_windows); ++w)
     if (int rc = enqueue_pre(w)) return rc;
   for (int64_t w = 0; w < std::min<int64_t>(ana_ahead, n_windows); ++w)
@@ -1931,7 +2009,8 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
       const hipStream_t ds = e->pipe.stream;
       const int64_t chain_tw = (int64_t)cb * std::max<int64_t>(1, 2880 / cb);
       AF_HIP(hipStreamWaitEvent(ds, syn_done[w], 0));
-      AF_HIP(hipMemsetAsync(e->d_stats + blocks_done * e->n_streams, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
+      if (clear_per_window)
+        AF_HIP(hipMemsetAsync(e->d_stats + blocks_done * e->n_streams, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, ds));
       e->last_kernel_used = AF_KERNEL_STAGED;
       e->pipe.call_stride = stream_stride;
       int64_t sub_blocks = 0;
@@ -1994,11 +2073,16 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
           eq_needs_chain_done = false;
         }
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
-        AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
+        if (clear_per_window) AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
         power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
         AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
                                       rows_w, false, seg_n, stream_stride, e->n_streams, es, power_w));
         e->last_launches += 1;
+        if (persistent) {  // the running chain launch picks the window up from here
+          AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, es));
+          blocks_done += (seg_n + cb - 1) / cb;
+          continue;
+        }
         hipEvent_t eq_done;
         if (int rc2 = next_event(&eq_done)) return rc2;
         AF_HIP(hipEventRecord(eq_done, es));
@@ -2007,6 +2091,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         eq_offloaded = true;
       }
     }
+    if (persistent) return fail(AF_ERR_BACKEND, "internal: a window of a one-launch call could not take the EQ on the suppressor's side");
     if (!eq_offloaded) {
       AF_HIP(hipStreamWaitEvent(e->aux_stream, syn_done[w], 0));
       eq_needs_chain_done = true;
@@ -2015,7 +2100,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (!diag_skip_chain)
       rc = launch_chain_segment(e, run_w, run_modified, out + seg0, out + seg0, seg_n, stream_stride, layout,
                                 e->samples_processed + seg0, e->d_stats + blocks_done * e->n_streams, vad, e->aux_stream, stream,
-                                eq_offloaded, power_w);
+                                /*stats_cleared=*/!clear_per_window || eq_offloaded, power_w);
     if (rc) return rc;
     run = e->host_params;  // crossfade bookkeeping may have moved on
     if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);

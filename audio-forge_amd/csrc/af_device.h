@@ -171,6 +171,9 @@ struct LaunchArgs {
   const BlockStats *pre_stats;  // rows of the pre-pass launch (compressor-input block power), or null
   const double *pre_power;    // [blocks][n_streams] the same block power as a plain array (af_eq_systolic.hip as the pre-pass); wins over pre_stats
   const double *vad_prob;     // [blocks][n_streams] speech posteriors for auto-makeup, or null
+  const int64_t *ready;       // device counter or null: samples of `in` (launch-relative, every stream) that producers on other
+                              // streams have finished so far.  Set: the launch covers a whole call and follows the suppressor's
+                              // windows as they arrive (a chunk waits until the counter covers it) -- ONE launch per call
   int64_t n_samples;
   int64_t stream_stride;
   int64_t samples_before;     // samples processed by earlier launches (van-Herk phase)

@@ -67,10 +67,12 @@ __host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, 
 // (seconds) the workgroup-wide abort word is raised, every later wait falls through, and the
 // host reports the launch as failed instead of the GPU hanging.
 constexpr int kAbortSlot = 32;
+constexpr int kPatienceSlot = 33;  // != 0: the launch follows a ready counter; a token may then be away for as long as that wait is allowed to last
 #ifdef AF_TOKEN_PROFILE  // development aid (make EXTRA=-DAF_TOKEN_PROFILE): cycles every serial unit is waited for / held,
                          // printed by workgroup 0 at the end of each launch
 __shared__ unsigned g_prof[2][16][12];
 __shared__ long long g_prof_acq[16];
+__shared__ long long g_prof_ready[16];
 #endif
 __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
   __builtin_amdgcn_sched_barrier(0);
@@ -82,7 +84,7 @@ __device__ __forceinline__ void token_wait(int *turn_base, int tok, int q) {
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 0xfff) == 0) {
       if (__hip_atomic_load(&turn_base[kAbortSlot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-      if (spins > (1 << 25)) {
+      if (spins > (turn_base[kPatienceSlot] ? (1 << 28) : (1 << 25))) {
         __hip_atomic_store(&turn_base[kAbortSlot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
       }
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   const int64_t n0 = a.samples_before;  // absolute index of this launch's first sample
 
   // ---------------- stage the per-stream state into LDS (wave w takes rows w, w+16, ...)
-  if (tid < 64) turn[tid] = 0;
+  if (tid < 64) turn[tid] = (tid == kPatienceSlot && a.ready) ? 1 : 0;
 #ifdef AF_TOKEN_PROFILE
   for (int i = tid; i < 2 * 16 * 12; i += kRingWaves * kLanes) (&g_prof[0][0][0])[i] = 0;
-  const long long prof_k0 = clock64();
+  if (tid < 16) g_prof_ready[tid] = 0;
+  const long long prof_k0 = clock64(), prof_w0 = wall_clock64();
 #endif
   {
     struct Map { int row, field; };
@@ -245,6 +248,8 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   const bool vec_ok = a.layout == 0 && (cb % kChunk) == 0 && (a.stream_stride % 4) == 0 && (kChunk % 2) == 0 &&
                       ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
 
+  constexpr int64_t kAllReady = 0x7fffffffffffffffLL;
+  int64_t ready_seen = a.ready ? 0 : kAllReady;  // (wave-uniform)
   for (int64_t q64 = wave; q64 < Q; q64 += kRingWaves) {
     const int q = (int)q64;
     const int64_t b = q64 / cpb;
@@ -252,6 +257,32 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
     const int blk_len = (int)((a.n_samples - b * cb) < cb ? (a.n_samples - b * cb) : cb);
     const int64_t t0 = b * cb + (int64_t)i * kChunk;  // launch-relative index of the chunk's first sample
     const int len = (blk_len - i * kChunk) < kChunk ? (blk_len - i * kChunk) : kChunk;
+    if (t0 + len > ready_seen) {
+      // The launch follows its producers (a.ready): the chunk's samples -- and the block's pre-pass power -- are there once the
+      // counter covers them.  The wave holds no token here, so the waves ahead of it drain on.  Polls are relaxed agent-scope
+      // loads; ONE acquire fence after the last one makes the producers' writes (other XCDs: written back at their kernels' ends,
+      // the counter published after that) visible to this wave's loads.  Bounded: a counter that never arrives ends the wait after
+      // ~4 s, reports through the status word and lets every wave run to the end of the launch.
+      int spins = 0;
+#ifdef AF_TOKEN_PROFILE
+      const long long prof_r0 = clock64();
+#endif
+      for (;;) {
+        ready_seen = __hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ready_seen >= t0 + len) break;
+        __builtin_amdgcn_s_sleep(32);
+        if ((++spins & 0xff) == 0 &&
+            (spins > (1 << 22) || __hip_atomic_load(&turn[kAbortSlot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0)) {
+          __hip_atomic_store(&turn[kAbortSlot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ready_seen = kAllReady;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef AF_TOKEN_PROFILE
+      if ((threadIdx.x & 63) == 0) g_prof_ready[threadIdx.x >> 6] += clock64() - prof_r0;
+#endif
+    }
     const bool first_in_block = i == 0;
     const bool last_in_block = i * kChunk + len == blk_len;
     BlockStats *row = a.stats ? &a.stats[b * NS + sc] : nullptr;
@@ -880,8 +911,15 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   if (tid == 0 && turn[kAbortSlot] != 0 && a.status) atomicExch(a.status, 1);
 #ifdef AF_TOKEN_PROFILE
   if (tid == 0 && blockIdx.x == 0 && Q > 0) {
-    printf("ring profile: %lld chunks, kernel %lld ticks = %.1f per chunk\n", (long long)Q, (long long)(clock64() - prof_k0),
-           (double)(clock64() - prof_k0) / (double)Q);
+    const long long ticks = clock64() - prof_k0, wall = wall_clock64() - prof_w0;  // shader cycles; 100 MHz constant clock
+    printf("ring profile: %lld chunks, kernel %lld ticks = %.1f per chunk, %.3f ms wall, clock %.3f GHz\n", (long long)Q, ticks,
+           (double)ticks / (double)Q, (double)wall * 1e-5, (double)ticks / ((double)wall * 10.0));
+    if (a.ready) {
+      long long r = 0;
+      for (int k = 0; k < kRingWaves; ++k) r += g_prof_ready[k];
+      printf("  waiting for the ready counter: %.3f ms per wave (wave 0: %.3f ms)\n",
+             (double)r / kRingWaves / ((double)ticks / ((double)wall * 1e-5)), (double)g_prof_ready[0] / ((double)ticks / ((double)wall * 1e-5)));
+    }
     for (int t = 0; t < kTokEq0 + n_groups; ++t) {
       long long w = 0, h = 0;
       for (int k = 0; k < kRingWaves; ++k) { w += g_prof[0][k][t]; h += g_prof[1][k][t]; }
@@ -996,6 +1034,16 @@ hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahe
                              bool auto_makeup, hipStream_t stream) {
   return launch_chain_ring_lds(args, ring_lds_bytes(n_sections, lookahead_samples, crossfade), variant, auto_makeup, stream);
 }
+// The producers' side of LaunchArgs::ready: enqueued on the producers' stream behind the kernel that completed the samples (its
+// writes are written back when it ends), one thread publishes the new count with an agent-scope release store.
+__global__ void chain_publish_ready_kernel(int64_t *ready, int64_t samples) {
+  __hip_atomic_store(ready, samples, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t launch_chain_publish_ready(int64_t *ready, int64_t samples, hipStream_t stream) {
+  hipLaunchKernelGGL(chain_publish_ready_kernel, dim3(1), dim3(1), 0, stream, ready, samples);
+  return hipGetLastError();
+}
+
 // `dyn`: dynamic LDS of the launch (several presets: the largest of their layouts, every workgroup lays out its own)
 hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream) {
   if (auto_makeup) {

@@ -431,21 +431,49 @@ __device__ __forceinline__ void fft960_wave(float2 *a, const FftShared &S, int l
 
 // ---- evaluation orders shared with the CPU restatement (oracle/af_rnnoise.c, "pitch tools") ----------
 // dot64: 64 interleaved partial sums (mul then add), xor-butterfly combine; every lane returns the total.
+// The xor butterfly 32, 16, 8, 4, 2, 1 of a wave-wide sum (every lane ends with the total), register to register: the same
+// additions in the same order as `acc + __shfl_xor(acc, off)`, which the compiler turns into six ds_bpermute_b32 round trips
+// through the LDS crossbar (~100 cycles each, and an s_waitcnt that also drains the kernel's other LDS traffic).  Stages 32 and
+// 16 are gfx950's v_permlane32_swap / v_permlane16_swap (both halves / neighbouring rows exchanged; a + b == b + a); stage 8 is
+// DPP row_ror:8 (lane i ^ 8 exactly); from there the partial sums repeat with period 8 across the wave, so row_ror:4 delivers
+// the value lane i ^ 4 holds, and stages 2 and 1 are quad permutes.
+template <int kBegin, int kEnd, typename F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(std::integral_constant<int, k>) for k in [kBegin, kEnd): indices stay constants
+  if constexpr (kBegin < kEnd) {
+    f(std::integral_constant<int, kBegin>{});
+    static_for<kBegin + 1, kEnd>(f);
+  }
+}
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), kCtrl, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_allsum_xor(float acc) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+    acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+    acc = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  acc = acc + dpp_move<0x128>(acc);  // row_ror:8
+  acc = acc + dpp_move<0x124>(acc);  // row_ror:4
+  acc = acc + dpp_move<0x4E>(acc);   // quad_perm:[2,3,0,1]
+  acc = acc + dpp_move<0xB1>(acc);   // quad_perm:[1,0,3,2]
+  return acc;
+}
 __device__ __forceinline__ float wave_dot64(const float *x, const float *y, int n, int lane) {
   float acc = 0.0f;
 #pragma unroll 4
   for (int i = lane; i < n; i += 64) acc = acc + x[i] * y[i];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-  return acc;
+  return wave_allsum_xor(acc);
 }
 // same with a stride-2 view of y (the 4x-decimated buffer is every second sample of the 2x one)
 __device__ __forceinline__ float wave_dot64_sq_stride2(const float *y, int n, int lane) {
   float acc = 0.0f;
   for (int i = lane; i < n; i += 64) acc = acc + y[2 * i] * y[2 * i];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-  return acc;
+  return wave_allsum_xor(acc);
 }
 
 // compute_band_energy / compute_band_corr: band b = R_b + F_b, the rising ramp over band b-1's bins and the
@@ -752,9 +780,7 @@ extern "C" __global__ __launch_bounds__(64, 4) void supp_pitchsearch_kernel(Supp
       {
         float acc = 0.0f;
         for (int i = lane; i < len; i += 64) acc = acc + L.d4[i] * L.d4[i];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-        Syy0 = 1.0f + acc;
+        Syy0 = 1.0f + wave_allsum_xor(acc);
       }
       __syncthreads();
       static_assert(mp == 147, "coarse lag count");
@@ -1024,9 +1050,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
     {
       float acc = 0.0f;
       for (int i = lane; i < len; i += 64) acc = acc + S.c.d4[i] * S.c.d4[i];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
-      Syy0 = 1.0f + acc;
+      Syy0 = 1.0f + wave_allsum_xor(acc);
     }
     wave_lds_fence();
     static_assert(mp == 147, "coarse lag count");
@@ -1093,19 +1117,37 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
   float last_gain = st[SuppState::kLastGain];
   int memid = (int)st[SuppState::kMemId];
   for (int i = lane; i < kCepsMem * kRnnBands; i += 64) (&L.ceps[0][0])[i] = st[SuppState::kCeps + i];
-  float dctcol[kRnnBands];  // column `lane` of the DCT matrix (lanes < 22)
-#pragma unroll
-  for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + (lane < kRnnBands ? lane : 0)];
   __syncthreads();
 
+  // The frame's inputs (whitened buffer, band energies, the search's pitch index) are fetched one frame ahead, into registers: the
+  // loop is one dependent chain per stream, and an unhidden trip to HBM per frame was a tenth of it.
+  constexpr int kDsRegs = (kPitchBuf / 2 + 63) / 64;  // 14
+  float ds_next[kDsRegs];
+  float ex_next = 0.0f;
+  int pitch_next = 0;
+  auto prefetch = [&](int f) {
+    const SuppFrameRec *rn = a.rec + ((int64_t)f * a.n_streams + s);
+    const float *dsg = a.ds + ((int64_t)f * a.n_streams + s) * (kPitchBuf / 2);
+#pragma unroll
+    for (int k2 = 0; k2 < kDsRegs; ++k2) {
+      const int i = lane + 64 * k2;
+      ds_next[k2] = i < kPitchBuf / 2 ? dsg[i] : 0.0f;
+    }
+    ex_next = lane < kRnnBands ? rn->Ex[lane] : 0.0f;
+    pitch_next = rn->pitch_index;
+  };
+  if (a.n_frames > 0) prefetch(0);
   for (int f = 0; f < a.n_frames; ++f) {
     SuppFrameRec *rec = a.rec + ((int64_t)f * a.n_streams + s);
-    if (lane < kRnnBands) L.Ex[lane] = rec->Ex[lane];
-    {
-      const float *dsg = a.ds + ((int64_t)f * a.n_streams + s) * (kPitchBuf / 2);
-      for (int i = lane; i < kPitchBuf / 2; i += 64) L.ds[i] = dsg[i];
+    if (lane < kRnnBands) L.Ex[lane] = ex_next;
+#pragma unroll
+    for (int k2 = 0; k2 < kDsRegs; ++k2) {
+      const int i = lane + 64 * k2;
+      if (i < kPitchBuf / 2) L.ds[i] = ds_next[k2];
     }
-    int pitch_index = rec->pitch_index;
+    int pitch_index = __builtin_amdgcn_readfirstlane(pitch_next);  // (the same word on every lane: keep what follows from it scalar)
+    const float ex_mine = ex_next;  // band `lane`'s energy (lanes < 22)
+    if (f + 1 < a.n_frames) prefetch(f + 1);
     __syncthreads();
     // ---------------- remove_doubling(ds, 768, 60, 960, &pitch_index, last_period, last_gain)
     float gain;
@@ -1149,17 +1191,39 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
       const float g0 = xy / sqrtf(1 + xx * yy);
       float g = g0;
       int T = T0;
-      for (int k2 = 2; k2 <= 15; ++k2) {
+      // The candidates' lags depend on T0 alone, so all their correlations are formed first, as independent work (the decision
+      // loop below is a dependent chain; with the two dot products inside it every one of them paid its LDS round trip alone).
+      float xy_k[16], yy_k[16];
+      int T1_k[16];
+      static_for<2, 16>([&](auto k_tag) {
+        constexpr int k2 = decltype(k_tag)::value;
         const int T1 = (2 * T0 + k2) / (2 * k2);
-        if (T1 < minperiod) break;
         int T1b;
         if (k2 == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
         else {
-          const int sc2 = (k2 == 6 || k2 == 12) ? 5 : ((k2 & 1) ? 2 : 3);  // second_check[k]
+          constexpr int sc2 = (k2 == 6 || k2 == 12) ? 5 : ((k2 & 1) ? 2 : 3);  // second_check[k]
           T1b = (2 * sc2 * T0 + k2) / (2 * k2);
         }
-        xy = .5f * (wave_dot64(x, x - T1, N, lane) + wave_dot64(x, x - T1b, N, lane));
-        yy = .5f * (L.ylk[T1] + L.ylk[T1b]);
+        T1_k[k2] = T1;
+        if (T1 >= minperiod) {  // (wave-uniform)
+          // (every lane holds the same sums: parked in scalar registers, fourteen pairs of them would not fit the 80 vector ones)
+          xy_k[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(
+              __float_as_int(.5f * (wave_dot64(x, x - T1, N, lane) + wave_dot64(x, x - T1b, N, lane)))));
+          yy_k[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(.5f * (L.ylk[T1] + L.ylk[T1b]))));
+        } else {
+          xy_k[k2] = 0.0f;
+          yy_k[k2] = 0.0f;
+        }
+        if (k2 & 1) __builtin_amdgcn_sched_barrier(0);  // four dot products in flight at a time: more and the 80 registers spill
+      });
+      bool past_min = false;  // (the reference's loop breaks at the first candidate below the minimum period)
+      static_for<2, 16>([&](auto k_tag) {
+        constexpr int k2 = decltype(k_tag)::value;
+        const int T1 = T1_k[k2];
+        if (T1 < minperiod) past_min = true;
+        if (past_min) return;
+        xy = xy_k[k2];
+        yy = yy_k[k2];
         const float g1 = xy / sqrtf(1 + xx * yy);
         float cont;
         const int dT = T1 - prev_period;
@@ -1175,7 +1239,7 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
           T = T1;
           g = g1;
         }
-      }
+      });
       best_xy = fmaxf(0.0f, best_xy);
       float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1);
       const float c0 = wave_dot64(x, x - (T - 1), N, lane);
@@ -1192,17 +1256,31 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
     last_period = pitch_index;
     last_gain = gain;
     // ---------------- features that do not need the pitch spectrum (denoise.c compute_frame_features)
+    // column `lane` of the DCT matrix (lanes < 22), fetched here (L2 hits, hidden behind the logarithm and the scan) instead of
+    // held across the frame: the candidate correlations above need the registers
+    float dctcol[kRnnBands];
+    {
+      int col = lane < kRnnBands ? lane : 0;
+      asm volatile("" : "+v"(col));  // (per frame: the compiler must not hoist the 22 loads out of the frame loop again)
+#pragma unroll
+      for (int j = 0; j < kRnnBands; ++j) dctcol[j] = tb.dct[j * kRnnBands + col];
+    }
     float E = 0.0f;
     {
-      float logMax = -2, follow = -2;
+      // lane i takes band i's logarithm (every lane used to take all 22, ~40 instructions each: two fifths of this kernel's
+      // instructions); the floor-following scan over the bands stays in band order, on values read lane by lane
+      const float ly_raw = log10f(1e-2f + ex_mine);
+      float logMax = -2, follow = -2, ly_mine = 0.0f;
+#pragma unroll
       for (int i = 0; i < kRnnBands; ++i) {
-        float ly = log10f(1e-2f + L.Ex[i]);
+        float ly = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly_raw), i));
         ly = fmaxf(logMax - 7, fmaxf(follow - 1.5f, ly));
-        if (lane == 0) L.Ly[i] = ly;
+        if (lane == i) ly_mine = ly;
         logMax = fmaxf(logMax, ly);
         follow = fmaxf(follow - 1.5f, ly);
-        E += L.Ex[i];
+        E += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex_mine), i));
       }
+      if (lane < kRnnBands) L.Ly[lane] = ly_mine;
     }
     const bool silence = E < 0.04f;
     if (lane < kRnnFeatPad) L.feat[lane] = 0.0f;
@@ -1239,15 +1317,17 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
         L.dist[i][j] = dist;
       }
       __syncthreads();
-      if (lane == 0) {
-        float spec_variability = 0;
-        for (int i = 0; i < kCepsMem; ++i) {
-          float mindist = 1e15f;
+      {  // lane i < 8: the nearest other frame of the cepstral ring; the sum over i in order (one lane used to walk all 64 pairs)
+        float mindist = 1e15f;
+        if (lane < kCepsMem) {
+#pragma unroll
           for (int j = 0; j < kCepsMem; ++j)
-            if (j != i) mindist = fminf(mindist, L.dist[i][j]);
-          spec_variability += mindist;
+            if (j != lane) mindist = fminf(mindist, L.dist[lane][j]);
         }
-        L.feat[kRnnBands + 19] = spec_variability / kCepsMem - 2.1f;
+        float spec_variability = 0;
+#pragma unroll
+        for (int i = 0; i < kCepsMem; ++i) spec_variability += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mindist), i));
+        if (lane == 0) L.feat[kRnnBands + 19] = spec_variability / kCepsMem - 2.1f;
       }
     }
     __syncthreads();
