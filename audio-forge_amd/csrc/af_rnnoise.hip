@@ -469,6 +469,20 @@ __device__ __forceinline__ float wave_dot64(const float *x, const float *y, int 
   for (int i = lane; i < n; i += 64) acc = acc + x[i] * y[i];
   return wave_allsum_xor(acc);
 }
+// The same sum for a length known at compile time (every call site's is): written out, the reads carry immediate offsets and only
+// the last, partial round is masked -- the counted loop spent three instructions per round on its bookkeeping beside the one
+// multiply-add (the pitch tracker forms 33 such sums of 240 products per frame, the search 16 of up to 864).
+template <int kN>
+__device__ __forceinline__ float wave_dot64_n(const float *x, const float *y, int lane) {
+  float acc = 0.0f;
+  const float *xl = x + lane, *yl = y + lane;
+#pragma unroll
+  for (int k = 0; k < (kN + 63) / 64; ++k) {
+    if (64 * k + 63 < kN) acc = acc + xl[64 * k] * yl[64 * k];
+    else if (lane < kN - 64 * k) acc = acc + xl[64 * k] * yl[64 * k];
+  }
+  return wave_allsum_xor(acc);
+}
 // same with a stride-2 view of y (the 4x-decimated buffer is every second sample of the 2x one)
 __device__ __forceinline__ float wave_dot64_sq_stride2(const float *y, int n, int lane) {
   float acc = 0.0f;
@@ -943,8 +957,10 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   float n0, n1, n2, n3, n4;
   {
     float ac[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) ac[k] = wave_dot64(ds + k, ds, kPitchBuf / 2 - k, lane);
+    static_for<0, 5>([&](auto k_tag) {
+      constexpr int k = decltype(k_tag)::value;
+      ac[k] = wave_dot64_n<kPitchBuf / 2 - k>(ds + k, ds, lane);
+    });
     ac[0] *= 1.0001f;
     for (int i = 1; i <= 4; ++i) ac[i] -= ac[i] * (.008f * i) * (.008f * i);
     float lpc[4] = {0, 0, 0, 0};
@@ -1076,7 +1092,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
           const int d0 = i - 2 * best0;
           if (d0 <= 2 && d0 >= -2) continue;  // already done for the first candidate
         }
-        const float v = fmaxf(-1.0f, wave_dot64(x_lp, ds + i, len, lane));
+        const float v = fmaxf(-1.0f, wave_dot64_n<len>(x_lp, ds + i, lane));
         if (lane == 0) {
           S.f.xc[i] = v;
           const float x16 = v * 1e-12f;
@@ -1085,7 +1101,7 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
       }
     }
     AF_PS_STAMP(6);  // fine correlations
-    const float Syy0 = 1.0f + wave_dot64(ds, ds, len, lane);
+    const float Syy0 = 1.0f + wave_dot64_n<len>(ds, ds, lane);
     wave_lds_fence();
     best_pitch_scan_wave<mp>(S.f.numa, S.f.da, S.f.syy, Syy0, lane, best0, best1);
   }
@@ -1158,8 +1174,8 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
       const int prev_period = last_period / 2;
       const float *x = L.ds + maxperiod;
       if (T0 >= maxperiod) T0 = maxperiod - 1;
-      const float xx = wave_dot64(x, x, N, lane);
-      float xy = wave_dot64(x, x - T0, N, lane);
+      const float xx = wave_dot64_n<N>(x, x, lane);
+      float xy = wave_dot64_n<N>(x, x - T0, lane);
       {
         // yy_lookup[i] = max(0, xx + prefix_i), prefix over e_i = x[-i]^2 - x[N-i]^2 in the blocked scan order
         const int chunk = (maxperiod + 63) / 64;  // 6
@@ -1208,7 +1224,7 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
         if (T1 >= minperiod) {  // (wave-uniform)
           // (every lane holds the same sums: parked in scalar registers, fourteen pairs of them would not fit the 80 vector ones)
           xy_k[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(
-              __float_as_int(.5f * (wave_dot64(x, x - T1, N, lane) + wave_dot64(x, x - T1b, N, lane)))));
+              __float_as_int(.5f * (wave_dot64_n<N>(x, x - T1, lane) + wave_dot64_n<N>(x, x - T1b, lane)))));
           yy_k[k2] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(.5f * (L.ylk[T1] + L.ylk[T1b]))));
         } else {
           xy_k[k2] = 0.0f;
@@ -1242,9 +1258,9 @@ extern "C" __global__ __launch_bounds__(64, 6) void supp_pitch_kernel(SuppArgs a
       });
       best_xy = fmaxf(0.0f, best_xy);
       float pg = (best_yy <= best_xy) ? 1.0f : best_xy / (best_yy + 1);
-      const float c0 = wave_dot64(x, x - (T - 1), N, lane);
-      const float c1v = wave_dot64(x, x - T, N, lane);
-      const float c2 = wave_dot64(x, x - (T + 1), N, lane);
+      const float c0 = wave_dot64_n<N>(x, x - (T - 1), lane);
+      const float c1v = wave_dot64_n<N>(x, x - T, lane);
+      const float c2 = wave_dot64_n<N>(x, x - (T + 1), lane);
       int offset = 0;
       if ((c2 - c0) > .7f * (c1v - c0)) offset = 1;
       else if ((c0 - c2) > .7f * (c1v - c2)) offset = -1;
