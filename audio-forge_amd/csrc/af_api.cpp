@@ -1700,10 +1700,14 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         }
       return v;
     }();
-    static const bool ramp_down = [] {  // AF_SUPP_RAMP_END=0: no mirror image at the end of the call
+    // The mirror image at the end of the call shortens what runs after the suppressor's last kernel -- when that is the stage
+    // pipeline emptying.  Behind the token-ring kernel the chain is the longer side and trails the suppressor by more than a
+    // window anyway: there the small windows only cost launches (189.3 against 190.0 ms per bench step).  AF_SUPP_RAMP_END=0 / 1.
+    static const int ramp_down_env = [] {
       const char *env = std::getenv("AF_SUPP_RAMP_END");
-      return !env || std::atoi(env) != 0;
+      return env ? std::atoi(env) : -1;
     }();
+    const bool ramp_down = ramp_down_env >= 0 ? ramp_down_env != 0 : e->pipe.active;
     if (!up_env.empty()) {
       for (int64_t n : up_env) up.push_back(std::min<int64_t>(window, ((n + unit - 1) / unit) * unit));
     } else {
