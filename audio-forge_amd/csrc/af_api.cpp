@@ -457,7 +457,9 @@ int check_device_status(af_engine *e) {
   if (!e->d_status) return AF_OK;
   int32_t st = 0;
   AF_HIP(hipMemcpy(&st, e->d_status, sizeof st, hipMemcpyDeviceToHost));
-  if (st != 0) return fail(AF_ERR_BACKEND, "a chain kernel abandoned a stage token (device status %d); results are invalid", st);
+  if (st != 0)
+    return fail(AF_ERR_BACKEND, "a chain kernel abandoned a stage token (device status %d); results are invalid.  (A one-launch call "
+                                "waits for kernels on other streams: if something serialises dispatches, set AF_CHAIN_PERSISTENT=0.)", st);
   return AF_OK;
 }
 
@@ -577,6 +579,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
   // the window's pre-pass: an auto-makeup segment is then ONE launch
   // `ready`: the segment is a whole call whose input arrives window by window (LaunchArgs::ready); only the plain one-launch form
   // of the token-ring kernel follows such a counter -- the caller has checked that this is what the configuration takes
+  const bool followed_counter = ready != nullptr;
   if (ready && (!e->extra_presets.empty() || e->kernel == AF_KERNEL_ROLES || roles_mode() != 0))
     return fail(AF_ERR_BACKEND, "internal: only the plain token-ring launch follows a ready counter");
   if (!e->extra_presets.empty())
@@ -823,7 +826,7 @@ int launch_chain_segment(af_engine *e, const af::ChainParams &run_in, bool run_m
     AF_HIP(hipEventRecord(t1, stream));
     e->chain_ms_events.push_back({t0, t1});
   }
-  advance_crossfades(e, n_samples);
+  if (!followed_counter) advance_crossfades(e, n_samples);  // (a one-launch call: the caller moves the counters window by window)
   return AF_OK;
 }
 
@@ -1861,7 +1864,15 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   // AF_CHAIN_PERSISTENT=0 restores one launch per window (A/B runs).
   static const bool persistent_env = [] {
     const char *env = std::getenv("AF_CHAIN_PERSISTENT");
-    return !env || std::atoi(env) != 0;
+    if (env) return std::atoi(env) != 0;
+    // The launch waits for kernels on other streams: it needs them to run beside it.  Tools that serialise dispatches make that
+    // impossible (the wait would run into its bound and the call would fail): counter collection of rocprofv3 (`--pmc`), the
+    // runtime's serialising debug switches.
+    for (const char *name : {"ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
+      const char *v = std::getenv(name);
+      if (v && std::atoi(v) != 0) return false;
+    }
+    return true;
   }();
   bool persistent = persistent_env && eq_offload && !clear_per_window && e->partition_chain_cus > 0 && !e->pipe.active &&
                     !std::getenv("AF_DIAG_SKIP_CHAIN") && e->extra_presets.empty() && roles_mode() == 0 &&
@@ -1869,7 +1880,6 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
                     !(run.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass)) && run.n_eq_sections <= 16 &&
                     af::ring_kernel_dynamic_lds(run.n_eq_sections, run.lim.lookahead_samples, false) <= af::kMaxLdsBytes &&
                     (!auto_makeup_call || e->d_block_power != nullptr) && win_f0.size() >= 2;
-  for (int j = 0; j < run.n_eq_sections && persistent; ++j) persistent = run.eq[j].xf_remaining == 0;
   if (persistent) {
     if (!e->d_ready) AF_HIP(hipMalloc(&e->d_ready, sizeof(int64_t)));
     AF_HIP(hipMemsetAsync(e->d_ready, 0, sizeof(int64_t), stream));
@@ -2044,7 +2054,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
     if (eq_offload && !diag_skip_chain) {
       const int n_presets = 1 + (int)e->extra_presets.size();
-      bool ok = true;
+      bool ok = true, xf_w = false;
       std::vector<af::ChainParams> runs_eq((size_t)n_presets);
       for (int k = 0; k < n_presets && ok; ++k) {
         runs_eq[k] = preset_params(e, k);
@@ -2052,7 +2062,9 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         const af::ChainParams &hp = runs_eq[k];
         ok = !(hp.flags & af::kFlagDeesser) && hp.n_eq_sections <= 16 && !(hp.flags & (af::kFlagDcBlock | af::kFlagPreHighpass)) &&
              af::ring_kernel_dynamic_lds(hp.n_eq_sections, hp.lim.lookahead_samples, false) <= af::kMaxLdsBytes;
-        for (int j = 0; j < hp.n_eq_sections; ++j) ok = ok && hp.eq[j].xf_remaining == 0;
+        // (a pending coefficient crossfade -- the 72 samples the legacy setters open a stream with -- runs in the systolic
+        // kernel's general form; round 2 kept such windows' EQ inside the chain launch)
+        for (int j = 0; j < hp.n_eq_sections; ++j) xf_w = xf_w || hp.eq[j].xf_remaining > 0;
       }
       if (ok) {
         const hipStream_t es = e->eq_stream;  // behind the window's overlap-add, beside the next window's synthesis
@@ -2080,10 +2092,13 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         if (clear_per_window) AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
         power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
         AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
-                                      rows_w, false, seg_n, stream_stride, e->n_streams, es, power_w));
+                                      rows_w, xf_w, seg_n, stream_stride, e->n_streams, es, power_w));
         e->last_launches += 1;
         if (persistent) {  // the running chain launch picks the window up from here
           AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, es));
+          advance_crossfades(e, seg_n);  // (the one chain launch did not: the EQ's counters move window by window)
+          run = e->host_params;
+          if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
           blocks_done += (seg_n + cb - 1) / cb;
           continue;
         }

@@ -448,7 +448,8 @@ def main() -> None:
                    5: "chain_comp_roles_kernel + chain_lim_roles_kernel (role pipeline)"}.get(used, "?")
     if rank == 0:
         # dominant kernel: the chain launch (HIP events recorded by the engine around it on the stream it runs on)
-        # (with the suppressor on the chain runs once per window, so a step holds several launches)
+        # (behind the suppressor the chain is ONE launch per call that follows the windows as they arrive -- its duration then
+        # includes what it waits for them; configurations that keep one launch per window report their average)
         launches = max(1, int(segments))
         avg_kernel_s = float(np.mean(first_ms)) / 1000.0 / launches
         frames_per_launch = streams * n // launches
@@ -469,7 +470,10 @@ def main() -> None:
         if prof is not None:
             row = next((v for k, v in prof["kernels"].items() if kernel_name.split("<")[0].split(" ")[0] in k), None)
             if row is not None:
-                per_launch = row["launches_per_step"]
+                # the file holds per-STEP totals; a launch of THIS run is 1 / launches of a step (the counter passes themselves
+                # run one chain launch per window: rocprofv3 --pmc serialises dispatches, and a launch that follows its
+                # producers' counter needs them beside it -- the engine falls back by itself there)
+                per_launch = launches
                 roofline["traffic"] = (row["fetch_bytes"] + row["write_bytes"]) / per_launch  # HBM bytes per launch (PMC)
                 cus = min(chain_groups, 256)
                 t_kernel = avg_kernel_s
@@ -492,7 +496,8 @@ def main() -> None:
             if full:
                 roofline["mfma"] = mfma_block(prof, streams, n // 480)
             roofline["counters_from"] = {"file": prof["_file"], "commit": prof.get("commit"),
-                                         "note": "separate rocprofv3 --pmc runs of this command; not measured in this run"}
+                                         "note": "separate rocprofv3 --pmc runs of this command (per-step totals; taken with one chain launch per "
+                                                 "window, which is what the engine does under a serialising profiler); not measured in this run"}
         line = {
             "metric": "48 kHz mono frames/s (real-time-factor x streams), voice chain",
             "value": value,
