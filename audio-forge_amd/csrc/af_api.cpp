@@ -474,6 +474,21 @@ int roles_mode() {
   return mode;
 }
 
+// AF_CHAIN_PERSISTENT=0 / 1; default on, except under tools that serialise dispatches: a launch that waits for kernels on other
+// streams needs them to run beside it (counter collection of rocprofv3 `--pmc`, the runtime's blocking-launch debug switches).
+bool one_launch_calls_enabled() {
+  static const bool on = [] {
+    const char *env = std::getenv("AF_CHAIN_PERSISTENT");
+    if (env) return std::atoi(env) != 0;
+    for (const char *name : {"ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
+      const char *v = std::getenv(name);
+      if (v && std::atoi(v) != 0) return false;
+    }
+    return true;
+  }();
+  return on;
+}
+
 // after a launch of n samples: advance the (stream-uniform) crossfade counters
 void advance_crossfades(af_engine *e, int64_t n) {
  for (int preset = 0; preset <= (int)e->extra_presets.size(); ++preset) {
@@ -1115,6 +1130,79 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
   return AF_OK;
 }
 
+// The engine's side streams (created once).  With queue CU masks: the chain stream on as many CUs as the chain has workgroups,
+// every other stream on the rest.
+int ensure_side_streams(af_engine *e, hipStream_t stream) {
+  if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
+    e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = stream;
+    e->borrowed_streams = true;
+  }
+
+  if (!e->aux_stream) {
+    // CU partition.  A 16-wave chain workgroup needs a whole CU (it fills the register file), and the suppressor's
+    // kernels keep thousands of small, some of them long-lived, workgroups in flight: left to the dispatcher, every chain
+    // launch waits for CUs to drain and runs beside strangers.  So the chain stream is confined to as many CUs as it has
+    // workgroups (mask bits 0.. select the same CU indices on every XCD: tools/probe/cu_mask_probe.hip) and the
+    // suppressor's streams to the rest; neither side ever waits for the other's workgroups to leave.
+    int chain_cus = 0;
+    const char *env = std::getenv("AF_CU_PARTITION");
+    const int chain_groups = (e->n_streams + 63) / 64;
+    hipDeviceProp_t prop;
+    AF_HIP(hipGetDeviceProperties(&prop, e->device));
+    const int total_cus = prop.multiProcessorCount;
+    if (!(env && std::atoi(env) == 0) && total_cus % 32 == 0 && total_cus <= 1024) {
+      // (a power of two: the workgroups of a launch are dealt to the XCDs in turn and 48 or 56 enabled CUs leave some of them
+      // with two workgroups each -- 3072 streams: 356 ms of chain launches per step on 48 CUs, 197 on 64)
+      int pow2 = 8;
+      while (pow2 < chain_groups) pow2 *= 2;
+      chain_cus = env && std::atoi(env) > 0 ? std::atoi(env) : pow2;
+      if (chain_cus * 2 > total_cus) chain_cus = 0;  // a chain that wants half the chip or more shares all of it
+    }
+    if (chain_cus > 0) {
+      // AF_ROLES=2: the limiter half of the chain gets CUs of its own (AF_LIM_CUS, default as many as the chain), taken from
+      // the suppressor's share
+      int lim_cus = 0;
+      if (roles_mode() == 2) {
+        const char *lenv = std::getenv("AF_LIM_CUS");
+        lim_cus = lenv ? std::atoi(lenv) : chain_cus;
+        if (lim_cus < 0 || chain_cus + lim_cus + 32 > total_cus) lim_cus = 0;
+      }
+      std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u), lim_mask(total_cus / 32, 0u);
+      // AF_CU_PATTERN (placement probe): 0 = the chain takes mask bits 0.. (CU indices 0.. of every XCD); 1 = every other CU
+      // index (bit / 8 even); 2 = the highest bits
+      static const int pattern = [] { const char *v = std::getenv("AF_CU_PATTERN"); return v ? std::atoi(v) : 0; }();
+      for (int bit = 0; bit < total_cus; ++bit) {
+        int rank = bit;  // the chain takes ranks 0 .. chain_cus-1
+        if (pattern == 1) rank = ((bit / 8) % 2 == 0) ? (bit / 16) * 8 + bit % 8 : total_cus / 2 + (bit / 16) * 8 + bit % 8;
+        else if (pattern == 2) rank = total_cus - 1 - bit;
+        (rank < chain_cus ? chain_mask : (rank < chain_cus + lim_cus ? lim_mask : rest_mask))[bit >> 5] |= 1u << (bit & 31);
+      }
+      hipError_t err = hipExtStreamCreateWithCUMask(&e->aux_stream, (uint32_t)chain_mask.size(), chain_mask.data());
+      if (err == hipSuccess && lim_cus > 0) err = hipExtStreamCreateWithCUMask(&e->lim_stream, (uint32_t)lim_mask.size(), lim_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->eq_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err != hipSuccess) {  // platform without queue CU masks: plain streams
+        (void)hipGetLastError();
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream, &e->lim_stream}) {
+          if (*sp) (void)hipStreamDestroy(*sp);
+          *sp = nullptr;
+        }
+        chain_cus = 0;
+      }
+    }
+    e->partition_chain_cus = chain_cus;
+  }
+  if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
+  if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
+  if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
+  if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
+  if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
+  return AF_OK;
+}
+
 // the EQ stage's parameter block for the window about to enter the pipeline (stream-ordered behind the previous window's launch)
 int stage_diag_eq_params(af_engine *e, hipStream_t stream, bool *crossfade, int32_t *slot_out) {
   const int n_presets = 1 + (int)e->extra_presets.size();
@@ -1638,6 +1726,86 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     }
   }
   if (!e->supp.enabled) {
+    // ---- Large batches without the suppressor (round 3): the chain can use one CU per 64 streams and nothing else, so the EQ
+    // -- a quarter of the token-ring kernel's time -- runs as the systolic kernel on the CUs the chain leaves idle, window by
+    // window, and the chain is ONE launch that follows it through the ready counter (the form the suppressor's pipeline
+    // uses).  Taken when the streams can be CU-partitioned and the EQ kernel serves the configuration.
+    {
+      const af::ChainParams &hp = e->host_params;
+      static const bool eq_offload_on = [] {
+        const char *env = std::getenv("AF_EQ_OFFLOAD");
+        return !env || std::atoi(env) != 0;
+      }();
+      const bool auto_mk = (hp.flags & af::kFlagCompressor) && hp.comp.auto_makeup_enabled;
+      const int64_t window = (int64_t)cb * std::max<int64_t>(1, 9600 / cb);
+      bool offload = one_launch_calls_enabled() && eq_offload_on && (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) &&
+                     (e->ring_variant == 0 || e->ring_variant == 1604) && e->extra_presets.empty() && roles_mode() == 0 &&
+                     layout == AF_LAYOUT_STREAM_MAJOR && (hp.flags & af::kFlagEq) && hp.n_eq_sections > 0 && hp.n_eq_sections <= 16 &&
+                     !(hp.flags & (af::kFlagDeesser | af::kFlagDcBlock | af::kFlagPreHighpass | af::kFlagPrePass)) &&
+                     af::ring_kernel_dynamic_lds(hp.n_eq_sections, hp.lim.lookahead_samples, true) <= af::kMaxLdsBytes &&
+                     n_samples >= 2 * window && !std::getenv("AF_SERIAL_STREAMS");
+      if (offload) {
+        if (int rc = ensure_side_streams(e, stream)) return rc;
+        offload = e->partition_chain_cus > 0 && !e->borrowed_streams;
+      }
+      if (offload) {
+        if (auto_mk) {
+          int64_t cap = e->block_power_capacity * (int64_t)sizeof(double);
+          if (int rc = grow_device(e, reinterpret_cast<void **>(&e->d_block_power), &cap, rows * (int64_t)sizeof(double), stream)) return rc;
+          e->block_power_capacity = cap / (int64_t)sizeof(double);
+        }
+        AF_HIP(hipMemsetAsync(e->d_stats, 0, sizeof(af::BlockStats) * rows, stream));
+        if (!e->d_ready) AF_HIP(hipMalloc(&e->d_ready, sizeof(int64_t)));
+        AF_HIP(hipMemsetAsync(e->d_ready, 0, sizeof(int64_t), stream));
+        hipEvent_t ev;
+        if (int rc = engine_event(e, &ev)) return rc;
+        AF_HIP(hipEventRecord(ev, stream));
+        AF_HIP(hipStreamWaitEvent(e->aux_stream, ev, 0));
+        AF_HIP(hipStreamWaitEvent(e->eq_stream, ev, 0));
+        af::ChainParams run_p = hp;  // the EQ kernel scrubs / clamps the input and keeps the block input statistics
+        run_p.flags = (run_p.flags & ~(af::kFlagEq | af::kFlagInputScrub | af::kFlagInputClamp)) | af::kFlagInputDone;
+        if (int rc = launch_chain_segment(e, run_p, true, out, out, n_samples, stream_stride, layout, e->samples_processed, e->d_stats,
+                                          e->has_evidence ? e->d_vad : nullptr, e->aux_stream, stream, /*stats_cleared=*/true,
+                                          auto_mk ? e->d_block_power : nullptr, e->d_ready))
+          return rc;
+        if (!e->d_params_eq || e->eq_params_presets != 1) {
+          if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));
+          e->d_params_eq = nullptr;
+          AF_HIP(hipMalloc(&e->d_params_eq, sizeof(af::ChainParams) * kEqParamSlots));
+          e->eq_params_presets = 1;
+          e->uploaded_eq.clear();
+        }
+        int64_t blocks_done = 0;
+        for (int64_t seg0 = 0; seg0 < n_samples; seg0 += window) {
+          const int64_t seg_n = std::min<int64_t>(window, n_samples - seg0);
+          std::vector<af::ChainParams> run_eq(1, e->host_params);  // (as the crossfade counters stand at this window)
+          bool xf_w = false;
+          for (int j = 0; j < run_eq[0].n_eq_sections; ++j) xf_w = xf_w || run_eq[0].eq[j].xf_remaining > 0;
+          if (e->uploaded_eq.size() != 1 || std::memcmp(e->uploaded_eq.data(), run_eq.data(), sizeof(af::ChainParams)) != 0) {
+            e->uploaded_eq = run_eq;
+            if (int rc = stage_upload(e, e->d_params_eq, run_eq.data(), 1, e->eq_stream)) return rc;
+          }
+          AF_HIP(af::launch_eq_systolic(e->d_params_eq, nullptr, e->d_st64, in + seg0, out + seg0, nullptr, nullptr, 0, 0,
+                                        e->d_stats + blocks_done * e->n_streams, xf_w, seg_n, stream_stride, e->n_streams, e->eq_stream,
+                                        auto_mk ? e->d_block_power + blocks_done * e->n_streams : nullptr));
+          AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, e->eq_stream));
+          e->last_launches += 2;
+          advance_crossfades(e, seg_n);
+          blocks_done += (seg_n + cb - 1) / cb;
+        }
+        for (hipStream_t side : {e->aux_stream, e->eq_stream}) {
+          if (int rc = engine_event(e, &ev)) return rc;
+          AF_HIP(hipEventRecord(ev, side));
+          AF_HIP(hipStreamWaitEvent(stream, ev, 0));
+        }
+        if (e->timing) {
+          AF_HIP(hipEventRecord(e->ev_mid, stream));
+          AF_HIP(hipEventRecord(e->ev_stop, stream));
+        }
+        e->samples_processed += n_samples;
+        return AF_OK;
+      }
+    }
     int rc = launch_chain_segment(e, e->host_params, false, in, out, n_samples, stream_stride, layout, e->samples_processed,
                                   e->d_stats, e->has_evidence ? e->d_vad : nullptr, stream, stream);
     if (rc) return rc;
@@ -1756,73 +1924,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     e->pipe.strip = e->host_params.flags & ~run.flags;  // what the pre-pass has taken over
     if (int rc = stage_chain_params(e, stream)) return rc;  // (everything but the EQ sections is read from here)
   }
-  if (std::getenv("AF_SERIAL_STREAMS")) {  // diagnostic: every stage on the caller's stream (per-kernel times without overlap)
-    e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = stream;
-    e->borrowed_streams = true;
-  }
-
-  if (!e->aux_stream) {
-    // CU partition.  A 16-wave chain workgroup needs a whole CU (it fills the register file), and the suppressor's
-    // kernels keep thousands of small, some of them long-lived, workgroups in flight: left to the dispatcher, every chain
-    // launch waits for CUs to drain and runs beside strangers.  So the chain stream is confined to as many CUs as it has
-    // workgroups (mask bits 0.. select the same CU indices on every XCD: tools/probe/cu_mask_probe.hip) and the
-    // suppressor's streams to the rest; neither side ever waits for the other's workgroups to leave.
-    int chain_cus = 0;
-    const char *env = std::getenv("AF_CU_PARTITION");
-    const int chain_groups = (e->n_streams + 63) / 64;
-    hipDeviceProp_t prop;
-    AF_HIP(hipGetDeviceProperties(&prop, e->device));
-    const int total_cus = prop.multiProcessorCount;
-    if (!(env && std::atoi(env) == 0) && total_cus % 32 == 0 && total_cus <= 1024) {
-      // (a power of two: the workgroups of a launch are dealt to the XCDs in turn and 48 or 56 enabled CUs leave some of them
-      // with two workgroups each -- 3072 streams: 356 ms of chain launches per step on 48 CUs, 197 on 64)
-      int pow2 = 8;
-      while (pow2 < chain_groups) pow2 *= 2;
-      chain_cus = env && std::atoi(env) > 0 ? std::atoi(env) : pow2;
-      if (chain_cus * 2 > total_cus) chain_cus = 0;  // a chain that wants half the chip or more shares all of it
-    }
-    if (chain_cus > 0) {
-      // AF_ROLES=2: the limiter half of the chain gets CUs of its own (AF_LIM_CUS, default as many as the chain), taken from
-      // the suppressor's share
-      int lim_cus = 0;
-      if (roles_mode() == 2) {
-        const char *lenv = std::getenv("AF_LIM_CUS");
-        lim_cus = lenv ? std::atoi(lenv) : chain_cus;
-        if (lim_cus < 0 || chain_cus + lim_cus + 32 > total_cus) lim_cus = 0;
-      }
-      std::vector<uint32_t> chain_mask(total_cus / 32, 0u), rest_mask(total_cus / 32, 0u), lim_mask(total_cus / 32, 0u);
-      // AF_CU_PATTERN (placement probe): 0 = the chain takes mask bits 0.. (CU indices 0.. of every XCD); 1 = every other CU
-      // index (bit / 8 even); 2 = the highest bits
-      static const int pattern = [] { const char *v = std::getenv("AF_CU_PATTERN"); return v ? std::atoi(v) : 0; }();
-      for (int bit = 0; bit < total_cus; ++bit) {
-        int rank = bit;  // the chain takes ranks 0 .. chain_cus-1
-        if (pattern == 1) rank = ((bit / 8) % 2 == 0) ? (bit / 16) * 8 + bit % 8 : total_cus / 2 + (bit / 16) * 8 + bit % 8;
-        else if (pattern == 2) rank = total_cus - 1 - bit;
-        (rank < chain_cus ? chain_mask : (rank < chain_cus + lim_cus ? lim_mask : rest_mask))[bit >> 5] |= 1u << (bit & 31);
-      }
-      hipError_t err = hipExtStreamCreateWithCUMask(&e->aux_stream, (uint32_t)chain_mask.size(), chain_mask.data());
-      if (err == hipSuccess && lim_cus > 0) err = hipExtStreamCreateWithCUMask(&e->lim_stream, (uint32_t)lim_mask.size(), lim_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->pre_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->eq_stream, (uint32_t)rest_mask.size(), rest_mask.data());
-      if (err != hipSuccess) {  // platform without queue CU masks: plain streams
-        (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream, &e->lim_stream}) {
-          if (*sp) (void)hipStreamDestroy(*sp);
-          *sp = nullptr;
-        }
-        chain_cus = 0;
-      }
-    }
-    e->partition_chain_cus = chain_cus;
-  }
-  if (!e->aux_stream) AF_HIP(hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking));
-  if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
-  if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
-  if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
-  if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
+  if (int rc = ensure_side_streams(e, stream)) return rc;
   static const bool split_synthesis = [] {  // AF_SYNTH_SPLIT=0: resynthesis + overlap-add stay behind the network on one stream
     const char *env = std::getenv("AF_SYNTH_SPLIT");
     return !env || std::atoi(env) != 0;
@@ -1862,18 +1964,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
   // cross-stream dependencies (~0.1 ms each while six other queues are busy: the trace of tools/step_timeline.py), the
   // state planes' load and write-back per window, and the fill / drain of the 16-wave pipeline per launch.
   // AF_CHAIN_PERSISTENT=0 restores one launch per window (A/B runs).
-  static const bool persistent_env = [] {
-    const char *env = std::getenv("AF_CHAIN_PERSISTENT");
-    if (env) return std::atoi(env) != 0;
-    // The launch waits for kernels on other streams: it needs them to run beside it.  Tools that serialise dispatches make that
-    // impossible (the wait would run into its bound and the call would fail): counter collection of rocprofv3 (`--pmc`), the
-    // runtime's serialising debug switches.
-    for (const char *name : {"ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"}) {
-      const char *v = std::getenv(name);
-      if (v && std::atoi(v) != 0) return false;
-    }
-    return true;
-  }();
+  const bool persistent_env = one_launch_calls_enabled();
   bool persistent = persistent_env && eq_offload && !clear_per_window && e->partition_chain_cus > 0 && !e->pipe.active &&
                     !std::getenv("AF_DIAG_SKIP_CHAIN") && e->extra_presets.empty() && roles_mode() == 0 &&
                     (e->kernel == AF_KERNEL_AUTO || e->kernel == AF_KERNEL_PHASED) && layout == AF_LAYOUT_STREAM_MAJOR &&

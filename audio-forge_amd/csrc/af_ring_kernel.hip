@@ -892,6 +892,12 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
+#ifndef AF_NO_FIN_PIN
+        // The fold below needs one number.  Left alone, LLVM sinks the 512 multiply-adds that produce it past the token's acquire
+        // (legal: earlier loads may move below an acquire) and the LAST serial unit holds its token for ~3 000 cycles per chunk --
+        // the longest unit of the kernel once the EQ has left it, i.e. its period.  Pinned here, the unit is a max and a store.
+        asm volatile("" : "+v"(otp));
+#endif
       }
       // ---- token: fold the chunk's output true peak into the block maximum
       if (out_detector) {
