@@ -66,6 +66,15 @@ __host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, 
 // Every wave reaches the end of the kernel even if a token never arrives: after ~2^25 polls
 // (seconds) the workgroup-wide abort word is raised, every later wait falls through, and the
 // host reports the launch as failed instead of the GPU hanging.
+// A feed-forward result pinned where it is written: LLVM may sink the arithmetic that produces a value used only inside a serial
+// unit past the unit's token wait (earlier loads and pure arithmetic may legally move below an acquire), where it lengthens the
+// time the token is held -- the kernel's period is its longest unit.  -DAF_NO_FF_PINS builds without (A/B).
+// AF_PIN_MASK (A/B builds): 1 = in front of the peak-envelope unit, 2 = gain-reduction smoothing, 4 = limiter, 8 = true-peak
+// limiter, 16 = final fold.
+#ifndef AF_PIN_MASK
+#define AF_PIN_MASK (2 | 16)
+#endif
+#define AF_PIN(bit, v) do { if constexpr (((AF_PIN_MASK) & (bit)) != 0) asm volatile("" : "+v"(v)); } while (0)
 constexpr int kAbortSlot = 32;
 constexpr int kPatienceSlot = 33;  // != 0: the launch follows a ready counter; a token may then be away for as long as that wait is allowed to last
 #ifdef AF_TOKEN_PROFILE  // development aid (make EXTRA=-DAF_TOKEN_PROFILE): cycles every serial unit is waited for / held,
@@ -535,6 +544,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
           }
         // ---- token C: log-domain peak envelope (compressor.rs:735-742)
         double peak_db[kChunk];
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) AF_PIN(1, inst_peak_db[k]);
         token_wait(turn, kTokCompC, q);
         {
           double pe = L64(kR64PeakEnvDb);
@@ -558,6 +570,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         // ---- token E: release-time meter + gain-reduction smoothing (compressor.rs:452-505,752-764)
         double gr_k[kChunk];
         double makeup_lin;
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) AF_PIN(2, target[k]);
         token_wait(turn, kTokCompE, q);
         {
           double gr = L64(kR64Gr), fast = L64(kR64FastEnv), slow = L64(kR64SlowEnv);
@@ -737,6 +752,9 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         float *ring = &l32[kR32LimRing * kLanes];
         float *suf = &l32[(kR32LimRing + W) * kLanes];
         // ---- token: lookahead limiter (limiter.rs:246-284), sliding max by block prefix/suffix maxima
+  #pragma unroll
+        for (int k = 0; k < kChunk; ++k)
+          if (kFull || k < len) AF_PIN(4, x[k]);  // (the compressor's gain applied: an exp10 per sample)
         token_wait(turn, kTokLim, q);
         {
           double g = L64(kR64LimGain);
@@ -797,7 +815,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
         // ---- feed-forward: input-side 4x true peak
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
-          if (kFull || k < len) itp[k] = tp_observe_ring(&l32[kR32Tpi * kLanes], nb + k, lane);
+          if (kFull || k < len) {
+            itp[k] = tp_observe_ring(&l32[kR32Tpi * kLanes], nb + k, lane);
+            AF_PIN(8, itp[k]);
+          }
       }
 
       // ---- token: true-peak gain (true_peak.rs:341-374), chain output, block output stats
@@ -892,12 +913,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
   #pragma unroll
         for (int k = 0; k < kChunk; ++k)
           if (kFull || k < len) otp = fmaxf(otp, tp_observe_ring(&l32[kR32Tpo * kLanes], nb + k, lane));
-#ifndef AF_NO_FIN_PIN
         // The fold below needs one number.  Left alone, LLVM sinks the 512 multiply-adds that produce it past the token's acquire
         // (legal: earlier loads may move below an acquire) and the LAST serial unit holds its token for ~3 000 cycles per chunk --
         // the longest unit of the kernel once the EQ has left it, i.e. its period.  Pinned here, the unit is a max and a store.
-        asm volatile("" : "+v"(otp));
-#endif
+        AF_PIN(16, otp);
       }
       // ---- token: fold the chunk's output true peak into the block maximum
       if (out_detector) {
