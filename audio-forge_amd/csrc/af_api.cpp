@@ -44,7 +44,7 @@ hipError_t launch_deesser(const ChainParams *d_params, double *st64, float *st32
 hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
                               int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream,
-                              double *block_power = nullptr);
+                              double *block_power = nullptr, int n_sections = -1);
 bool comp_roles_serves(const ChainParams &p);
 bool lim_roles_serves(const ChainParams &p);
 hipError_t launch_chain_comp_roles(const LaunchArgs &args, bool sidechain, bool adaptive, hipStream_t stream);
@@ -1787,7 +1787,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
           }
           AF_HIP(af::launch_eq_systolic(e->d_params_eq, nullptr, e->d_st64, in + seg0, out + seg0, nullptr, nullptr, 0, 0,
                                         e->d_stats + blocks_done * e->n_streams, xf_w, seg_n, stream_stride, e->n_streams, e->eq_stream,
-                                        auto_mk ? e->d_block_power + blocks_done * e->n_streams : nullptr));
+                                        auto_mk ? e->d_block_power + blocks_done * e->n_streams : nullptr));  // (the systolic form: here the EQ's own latency per window is what the chain follows)
           AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, e->eq_stream));
           e->last_launches += 2;
           advance_crossfades(e, seg_n);
@@ -2183,7 +2183,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         if (clear_per_window) AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
         power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
         AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
-                                      rows_w, xf_w, seg_n, stream_stride, e->n_streams, es, power_w));
+                                      rows_w, xf_w, seg_n, stream_stride, e->n_streams, es, power_w,
+                                      // the lane-per-stream form where the suppressor's kernels want the issue slots and nothing waits
+                                      // for the EQ's own latency (an auto-makeup window's block powers do): 184.5 -> 182.4 ms per step
+                                      (n_presets == 1 && !power_w && (runs_eq[0].flags & af::kFlagEq)) ? runs_eq[0].n_eq_sections : -1));
         e->last_launches += 1;
         if (persistent) {  // the running chain launch picks the window up from here
           AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, es));

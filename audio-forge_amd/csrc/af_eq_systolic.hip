@@ -20,6 +20,7 @@
 // statistics (sum of squares in f64 in sample order, peak) the chain kernel's input unit would have produced.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "af_dsp.h"
@@ -32,15 +33,160 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
   eq_systolic_body<kStats, kXf, kPower>(a, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same EQ with a LANE per stream (round 3): one wave takes 64 streams through every section, memories and coefficients in
+// registers, four samples per round written out so that the scheduler sees the (sample, section) grid and walks it along its
+// diagonals -- (n, k) needs (n, k-1)'s output and (n-1, k)'s memories, so ten sections give ten independent chains.  Per
+// stream and sample this is 11 instructions per section where the systolic form spends ~23 wave instructions per step of FOUR
+// streams (every lane of a 16-lane row executes the step, six of them idle for ten sections): a third of the issue slots,
+// on the CUs the suppressor's kernels need.  What it gives up is latency hiding by occupancy: 64 waves per 4096 streams, each
+// wanting a SIMD's whole issue rate (priority 2).  Same expressions in the same order as the systolic body and the chain
+// kernel's EQ units: the same bits.  Serves windows without a pending crossfade, one preset, stream-major audio with 16-byte
+// rows; everything else takes the systolic kernel.
+template <int kSec, bool kStats, bool kPower>
+__global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 64 + lane;
+  const bool valid = s < a.n_streams;
+  const int sc = valid ? s : a.n_streams - 1;
+  const int64_t NS = a.n_streams;
+  const ChainParams &P = a.params[0];
+  const uint32_t flags = P.flags;
+  const bool scrub = (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = (flags & kFlagInputClamp) != 0;
+  const int cb = P.control_block;
+  __builtin_amdgcn_s_setprio(2);
+  BiquadCoef c[kSec];
+  double z1[kSec], z2[kSec];
+#pragma unroll
+  for (int k = 0; k < kSec; ++k) {
+    const SectionParams &sp = P.eq[k];
+    c[k] = sp.xf_remaining > 0 ? sp.pending : sp.active;  // (a crossfade that ended in an earlier launch: see the systolic body)
+    z1[k] = a.st64[(int64_t)(kEqBase + 4 * k) * NS + sc];
+    z2[k] = a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + sc];
+  }
+  const float *row_in = a.in + (int64_t)sc * a.stream_stride;
+  float *row_out = a.audio + (int64_t)sc * a.stream_stride;
+  const int64_t n = a.n_samples;
+  double in_sq = 0.0, out_sq = 0.0;
+  float in_peak = 0.0f;
+  int64_t block_index = 0;
+  int in_block = 0;  // samples of the current control block done (wave-uniform)
+  auto sample = [&](float v) -> float {
+    if (scrub && !finite_f32(v)) v = 0.0f;
+    if (clamp) v = fclamp(v, -1.0f, 1.0f);
+    if (kStats) {
+      const double xd0 = (double)v;
+      in_sq += xd0 * xd0;
+      in_peak = fmaxf(in_peak, fabsf(v));
+    }
+    float x = v;
+#pragma unroll
+    for (int k = 0; k < kSec; ++k) {
+      const double xd = (double)x;
+      const double y = c[k].b0 * xd + z1[k];
+      z1[k] = c[k].b1 * xd - c[k].a1 * y + z2[k];
+      z2[k] = c[k].b2 * xd - c[k].a2 * y;
+      x = (float)y;
+    }
+    if (kPower) {
+      const double yd = (double)x;
+      out_sq += finite_f32(x) ? yd * yd : 0.0;
+    }
+    return x;
+  };
+  auto flush = [&]() {  // a control block (or the launch) has ended
+    if (kStats && valid && a.stats) {
+      BlockStats &r = a.stats[block_index * NS + s];
+      r.input_square_sum = in_sq;
+      r.input_sample_peak = in_peak;
+    }
+    if (kPower && valid) a.block_power[block_index * NS + s] = out_sq;
+    block_index += 1;
+    in_block = 0;
+    in_sq = 0.0;
+    in_peak = 0.0f;
+    out_sq = 0.0;
+  };
+  const int64_t quads = n >> 2;
+  // the loads run two rounds ahead of the arithmetic (a lane walks its own row: a 128-byte line serves eight rounds)
+  float4 v0 = quads > 0 ? *reinterpret_cast<const float4 *>(row_in) : make_float4(0, 0, 0, 0);
+  float4 v1 = quads > 1 ? *reinterpret_cast<const float4 *>(row_in + 4) : make_float4(0, 0, 0, 0);
+  for (int64_t q = 0; q < quads; ++q) {
+    const float4 v2 = q + 2 < quads ? *reinterpret_cast<const float4 *>(row_in + 4 * (q + 2)) : make_float4(0, 0, 0, 0);
+    float4 o;
+    if (in_block + 4 <= cb) {  // (wave-uniform) the plain round: no block boundary inside
+      o.x = sample(v0.x);
+      o.y = sample(v0.y);
+      o.z = sample(v0.z);
+      o.w = sample(v0.w);
+      in_block += 4;
+      if (in_block == cb) flush();
+    } else {  // a control block that is not a multiple of four samples long ends inside the round
+      float t[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[j] = sample(t[j]);
+        if (++in_block == cb) flush();
+      }
+      o = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    if (valid) *reinterpret_cast<float4 *>(row_out + 4 * q) = o;
+    v0 = v1;
+    v1 = v2;
+  }
+  for (int64_t t = quads * 4; t < n; ++t) {  // ragged end
+    const float o = sample(row_in[t]);
+    if (valid) row_out[t] = o;
+    if (++in_block == cb) flush();
+  }
+  if (in_block > 0) flush();  // a short last block
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < kSec; ++k) {
+      a.st64[(int64_t)(kEqBase + 4 * k) * NS + s] = z1[k];
+      a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + s] = z2[k];
+    }
+  }
+}
+
+template <int kSec>
+static void launch_eq_stream_sections(const EqSystolicArgs &a, bool stats, bool power, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.n_streams + 63) / 64)), block(64);
+  if (power) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, true>), grid, block, 0, stream, a);
+  else if (stats) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((eq_stream_kernel<kSec, false, false>), grid, block, 0, stream, a);
+}
+static bool launch_eq_stream(const EqSystolicArgs &a, int n_sections, bool stats, bool power, hipStream_t stream) {
+  switch (n_sections) {
+#define AF_EQ_STREAM_CASE(k) case k: launch_eq_stream_sections<k>(a, stats, power, stream); return true;
+    AF_EQ_STREAM_CASE(1) AF_EQ_STREAM_CASE(2) AF_EQ_STREAM_CASE(3) AF_EQ_STREAM_CASE(4) AF_EQ_STREAM_CASE(5) AF_EQ_STREAM_CASE(6)
+    AF_EQ_STREAM_CASE(7) AF_EQ_STREAM_CASE(8) AF_EQ_STREAM_CASE(9) AF_EQ_STREAM_CASE(10) AF_EQ_STREAM_CASE(11) AF_EQ_STREAM_CASE(12)
+    AF_EQ_STREAM_CASE(13) AF_EQ_STREAM_CASE(14) AF_EQ_STREAM_CASE(15) AF_EQ_STREAM_CASE(16)
+#undef AF_EQ_STREAM_CASE
+    default: return false;
+  }
+}
+
 // `audio`: stream-major output (may be `in`); or null and `ring` / `ring_in` / `ring_rows` / `n0`: the stage pipeline's rings.
 // `stats` null: no block input statistics.  `crossfade`: some section has a coefficient crossfade pending.
 // `block_power` ([block][stream], with `stats`): also the square sum of every control block of the filtered samples -- the
 // launch is then the pre-pass of an auto-makeup window.
 hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_group_preset, double *st64, const float *in, float *audio,
                               float *ring, float *ring_in, int32_t ring_rows, int64_t n0, BlockStats *stats, bool crossfade,
-                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream, double *block_power) {
+                              int64_t n_samples, int64_t stream_stride, int32_t n_streams, hipStream_t stream, double *block_power,
+                              int n_sections) {
   EqSystolicArgs a{d_params, d_group_preset, st64, in, audio, ring, ring_in, stats, n_samples, stream_stride, n0, n_streams, ring_rows,
                    block_power};
+  // `n_sections` > 0: the caller knows the (single) preset runs that many EQ sections -- the lane-per-stream kernel where it
+  // serves the launch (AF_EQ_STREAM=0: always the systolic kernel)
+  static const bool stream_form = [] {
+    const char *env = std::getenv("AF_EQ_STREAM");
+    return !env || std::atoi(env) != 0;
+  }();
+  if (stream_form && n_sections > 0 && !crossfade && !d_group_preset && audio && !ring && (stream_stride % 4) == 0 &&
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(audio)) & 15) == 0 && (!block_power || stats)) {
+    if (launch_eq_stream(a, n_sections, stats != nullptr, block_power != nullptr, stream)) return hipGetLastError();
+  }
   const dim3 grid((unsigned)((n_streams + 3) / 4)), block(64);
   if (block_power) {
     if (!stats) return hipErrorInvalidValue;
