@@ -891,10 +891,14 @@ __device__ __forceinline__ void best_pitch_scan_wave(const float *numa, const fl
 }
 
 constexpr int kPsFrames = 4;                                   // frames (waves) per workgroup
+constexpr int kPsX0 = 255;                                     // first data word of PsScan::c.x4z (17 x 15 guard words below it)
 constexpr int kPsRaw = kPitchBuf + (kPsFrames - 1) * kRnnFrame;  // samples of the shared span: 3168
 struct PsScan {  // a wave's scan arrays: the coarse stage's (d4, numa, da, syy over 147 lags), then the fine stage's (294 lags)
   union {
-    struct { float d4[kPitchBuf / 4]; float numa[152], da[152], syy[152]; float x4p[256]; } c;  // x4p: x[j] at j + (j >> 4)
+    // x4z: x[j] at kPsX0 + j + (j >> 4), zeros on both sides: the coarse correlation's B operand reads x[4 s + k - 16 c] for every
+    // step s and column c, 255 words below and 152 above the data for the lags that do not exist -- as zeros in memory they cost
+    // nothing, as a bounds test they were six vector instructions per matrix instruction
+    struct { float d4[kPitchBuf / 4]; float numa[152], da[152], syy[152]; float x4z[672]; } c;
     struct { float xc[304], numa[304], da[304], syy[304]; } f;
   };
 };
@@ -1025,13 +1029,16 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   {
     // coarse: 4x decimated, 147 lags x 240 products on the matrix cores (see the one-wave kernel above)
     constexpr int len = kRnnWindow >> 2, mp = (kPitchMax - 3 * kPitchMin) >> 2;
+    static_assert(kPsX0 + (len - 1) + ((len - 1) >> 4) < 672 && 3 + 4 * 95 + 23 + kPsX0 < 672, "x4z holds the data and both guards");
+    for (int i = lane; i < kPsX0; i += 64) S.c.x4z[i] = 0.0f;
+    for (int i = kPsX0 + len + ((len - 1) >> 4) + lane; i < 672; i += 64) S.c.x4z[i] = 0.0f;
     for (int i = lane; i < kPitchBuf / 4; i += 64) {
       const float v = ds[2 * i];
       S.c.d4[i] = v;
       // the B operand reads x[4 s + k - 16 c]: sixteen columns 16 apart -- two banks for a whole half-wave in the plain layout
       // (most of this kernel's 0.52 conflict / LDS-active ratio); one pad word per sixteen makes the column stride 17
       const int j = i - (kPitchMax >> 2);
-      if (j >= 0 && j < len) S.c.x4p[j + (j >> 4)] = v;
+      if (j >= 0 && j < len) S.c.x4z[kPsX0 + j + (j >> 4)] = v;
     }
     wave_lds_fence();
     {
@@ -1039,15 +1046,14 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
       v4f_ps acc = {0.0f, 0.0f, 0.0f, 0.0f};
       const int col = lane & 15, kq = lane >> 4;
       const float *ap = S.c.d4 + kq + col;          // y[4 s + k + i]
-      const float *x4 = S.c.x4p;                    // x[j] = x_lp[2 j] at j + (j >> 4)
-      int xi = kq - 16 * col;                       // 4 s + k - 16 c at s = 0
-#pragma unroll 4
+      // x[j] = x_lp[2 j] sits at kPsX0 + j + (j >> 4); j = 4 s + k - 16 c, k < 4, so j + floor(j / 16) = k - 17 c + 4 s + (s >> 2):
+      // a per-lane base and a compile-time offset per step
+      const float *bp = S.c.x4z + kPsX0 + kq - 17 * col;
+#pragma unroll
       for (int st = 0; st < 96; ++st) {
         const float av = ap[4 * st];
-        const bool in = (unsigned)xi < (unsigned)len;
-        const float bv = in ? x4[in ? xi + (xi >> 4) : 0] : 0.0f;
+        const float bv = bp[4 * st + (st >> 2)];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-        xi += 4;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
