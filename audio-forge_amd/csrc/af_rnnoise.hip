@@ -948,8 +948,15 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   if (live) {
     const float *pb = L.raw + wave * kRnnFrame;  // pitch_buf after shifting frame f in = pb[0 .. 1728)
     // ---------------- pitch_downsample (pitch.c): 2x decimation
-    for (int i = lane; i < kPitchBuf / 2; i += 64)
-      ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0]) : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
+    // (rounds written out: 864 = 13 x 64 + 32, the special first sample only in round 0)
+    static_for<0, (kPitchBuf / 2 + 63) / 64>([&](auto r_tag) {
+      constexpr int r = decltype(r_tag)::value;
+      const int i = lane + 64 * r;
+      if (64 * r + 63 < kPitchBuf / 2 || lane < kPitchBuf / 2 - 64 * r) {
+        if (r == 0) ds[i] = i == 0 ? .5f * (.5f * pb[1] + pb[0]) : .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
+        else ds[i] = .5f * (.5f * (pb[2 * i - 1] + pb[2 * i + 1]) + pb[2 * i]);
+      }
+    });
   }
   __syncthreads();  // every wave has left the span: its LDS now holds the scan arrays
   if (!live) return;
@@ -1000,27 +1007,43 @@ extern "C" __global__ __launch_bounds__(64 * kPsFrames, 4) void supp_pitchsearch
   AF_PS_STAMP(2);  // autocorrelation + LPC
   {
     // celt_fir5 with zero initial memory: y[i] = x[i] + n0 x[i-1] + ... + n4 x[i-5], in that order
-    float yv[14];
-    int cnt = 0;
-    for (int i = lane; i < kPitchBuf / 2; i += 64, ++cnt) {
-      float sum = ds[i];
-      sum += n0 * (i >= 1 ? ds[i - 1] : 0.0f);
-      sum += n1 * (i >= 2 ? ds[i - 2] : 0.0f);
-      sum += n2 * (i >= 3 ? ds[i - 3] : 0.0f);
-      sum += n3 * (i >= 4 ? ds[i - 4] : 0.0f);
-      sum += n4 * (i >= 5 ? ds[i - 5] : 0.0f);
-      yv[cnt] = sum;
-    }
+    constexpr int kRounds = (kPitchBuf / 2 + 63) / 64;  // 14, the last one half a wave
+    float yv[kRounds];
+    static_for<0, kRounds>([&](auto r_tag) {
+      constexpr int r = decltype(r_tag)::value;
+      const int i = lane + 64 * r;
+      float sum = 0.0f;
+      if (64 * r + 63 < kPitchBuf / 2 || lane < kPitchBuf / 2 - 64 * r) {
+        sum = ds[i];
+        if (r == 0) {  // (the filter's zero initial memory only shows in the first five samples)
+          sum += n0 * (i >= 1 ? ds[i >= 1 ? i - 1 : 0] : 0.0f);
+          sum += n1 * (i >= 2 ? ds[i >= 2 ? i - 2 : 0] : 0.0f);
+          sum += n2 * (i >= 3 ? ds[i >= 3 ? i - 3 : 0] : 0.0f);
+          sum += n3 * (i >= 4 ? ds[i >= 4 ? i - 4 : 0] : 0.0f);
+          sum += n4 * (i >= 5 ? ds[i >= 5 ? i - 5 : 0] : 0.0f);
+        } else {
+          sum += n0 * ds[i - 1];
+          sum += n1 * ds[i - 2];
+          sum += n2 * ds[i - 3];
+          sum += n3 * ds[i - 4];
+          sum += n4 * ds[i - 5];
+        }
+      }
+      yv[r] = sum;
+    });
     wave_lds_fence();
-    cnt = 0;
-    for (int i = lane; i < kPitchBuf / 2; i += 64, ++cnt) ds[i] = yv[cnt];
+    // the whitened buffer goes back to LDS and out to memory (the pitch tracker reads it) in one pass, while the search runs
+    float *dsg = a.ds + cell * (kPitchBuf / 2);
+    static_for<0, kRounds>([&](auto r_tag) {
+      constexpr int r = decltype(r_tag)::value;
+      const int i = lane + 64 * r;
+      if (64 * r + 63 < kPitchBuf / 2 || lane < kPitchBuf / 2 - 64 * r) {
+        ds[i] = yv[r];
+        dsg[i] = yv[r];
+      }
+    });
   }
   wave_lds_fence();
-  // the whitened buffer goes out now (the pitch tracker reads it), while the search runs
-  {
-    float *dsg = a.ds + cell * (kPitchBuf / 2);
-    for (int i = lane; i < kPitchBuf / 2; i += 64) dsg[i] = ds[i];
-  }
   AF_PS_STAMP(3);  // whitened + stored
   // ---------------- pitch_search(x_lp = ds + 384, y = ds, len 960, max_pitch 588)
   const int max_pitch = kPitchMax - 3 * kPitchMin;  // 588
