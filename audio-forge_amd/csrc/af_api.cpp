@@ -151,6 +151,7 @@ struct af_engine {
   std::vector<Retired> retired;
   hipStream_t syn_stream = nullptr;        // CU partition: pitch spectra + network + resynthesis (else the caller's stream)
   hipStream_t fin_stream = nullptr;        // resynthesis + overlap-add of window w beside pitch spectra + network of w+1
+  hipStream_t rnn_stream = nullptr;        // the network of window w beside the pitch spectra of w+1 (AF_RNN_STREAM=0: on syn_stream)
   hipStream_t lim_stream = nullptr;        // AF_ROLES=2: the limiter half of the chain (af_roles.hip) on CUs of its own
   hipStream_t eq_stream = nullptr;         // the window's systolic EQ (af_eq_systolic.hip), behind its overlap-add, beside the next window's synthesis
   int partition_chain_cus = 0;             // CUs reserved for the chain stream (0 = the streams are not masked)
@@ -1130,6 +1131,14 @@ int stage_diag_step(af_engine *e, const af::ChainParams &run, const StagePlan &p
   return AF_OK;
 }
 
+bool rnn_stream_wanted() {
+  static const bool on = [] {
+    const char *env = std::getenv("AF_RNN_STREAM");
+    return env && std::atoi(env) == 1;
+  }();
+  return on;
+}
+
 // The engine's side streams (created once).  With queue CU masks: the chain stream on as many CUs as the chain has workgroups,
 // every other stream on the rest.
 int ensure_side_streams(af_engine *e, hipStream_t stream) {
@@ -1183,10 +1192,12 @@ int ensure_side_streams(af_engine *e, hipStream_t stream) {
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->ana_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->syn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->fin_stream, (uint32_t)rest_mask.size(), rest_mask.data());
+      if (err == hipSuccess && rnn_stream_wanted()) err = hipExtStreamCreateWithCUMask(&e->rnn_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&e->eq_stream, (uint32_t)rest_mask.size(), rest_mask.data());
       if (err != hipSuccess) {  // platform without queue CU masks: plain streams
         (void)hipGetLastError();
-        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream, &e->lim_stream}) {
+        for (hipStream_t *sp : {&e->aux_stream, &e->pre_stream, &e->ana_stream, &e->syn_stream, &e->fin_stream, &e->eq_stream, &e->lim_stream,
+                                &e->rnn_stream}) {
           if (*sp) (void)hipStreamDestroy(*sp);
           *sp = nullptr;
         }
@@ -1199,6 +1210,7 @@ int ensure_side_streams(af_engine *e, hipStream_t stream) {
   if (!e->pre_stream) AF_HIP(hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
   if (!e->ana_stream) AF_HIP(hipStreamCreateWithFlags(&e->ana_stream, hipStreamNonBlocking));
   if (!e->fin_stream) AF_HIP(hipStreamCreateWithFlags(&e->fin_stream, hipStreamNonBlocking));
+  if (!e->rnn_stream && !e->borrowed_streams && rnn_stream_wanted()) AF_HIP(hipStreamCreateWithFlags(&e->rnn_stream, hipStreamNonBlocking));
   if (!e->eq_stream) AF_HIP(hipStreamCreateWithFlags(&e->eq_stream, hipStreamNonBlocking));
   return AF_OK;
 }
@@ -1316,6 +1328,7 @@ void af_engine_destroy(af_engine *e) {
   if (e->borrowed_streams) e->aux_stream = e->pre_stream = e->ana_stream = e->fin_stream = e->eq_stream = nullptr;
   if (e->lim_stream) (void)hipStreamDestroy(e->lim_stream);
   if (e->fin_stream) (void)hipStreamDestroy(e->fin_stream);
+  if (e->rnn_stream) (void)hipStreamDestroy(e->rnn_stream);
   if (e->eq_stream) (void)hipStreamDestroy(e->eq_stream);
   if (e->syn_stream) (void)hipStreamDestroy(e->syn_stream);
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
@@ -1930,6 +1943,16 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     return !env || std::atoi(env) != 0;
   }();
   const hipStream_t fin = split_synthesis ? e->fin_stream : nullptr;
+  // The network kernel (a dependent chain of matrix instructions per 16 streams: long, and light on the chip) on a stream of its
+  // own: behind the pitch spectra on ONE stream the pair took 3.0 of a window's 3.16 ms -- that stream was the pipeline's period.
+  // MEASURED AND OFF: the eighth stream alone -- created, not even used -- takes the step from 172 to 184 ms, and with the network
+  // on it 187-189 ms: HIP multiplexes a process's streams onto a handful of hardware queues, and one more stream makes two of
+  // the pipeline's stages share a queue (false serialisation).  AF_RNN_STREAM=1 creates and uses it (A/B runs).
+  static const bool rnn_own_stream = rnn_stream_wanted();
+  static const bool rnn_on_caller = [] {  // AF_RNN_STREAM=2
+    const char *env = std::getenv("AF_RNN_STREAM");
+    return env && std::atoi(env) == 2;
+  }();
   const hipStream_t syn = e->syn_stream ? e->syn_stream : stream;  // where the synthesis stage runs
   int64_t blocks_done = 0;
   std::vector<af::DiagWin> diag_wins;                 // the call's windows in the stage pipeline (one launch per step)
@@ -1986,6 +2009,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     if (fin && fin != stream) AF_HIP(hipStreamWaitEvent(fin, ev, 0));
     if (e->eq_stream != stream) AF_HIP(hipStreamWaitEvent(e->eq_stream, ev, 0));
     if (e->lim_stream) AF_HIP(hipStreamWaitEvent(e->lim_stream, ev, 0));
+    if (e->rnn_stream) AF_HIP(hipStreamWaitEvent(e->rnn_stream, ev, 0));
   }
   constexpr int kXh = af::SuppressorHost::kXhBuffers;
   // Pipeline depth.  The spectrum / record buffers of window w are free again when its synthesis has ended, and the synthesis
@@ -2087,7 +2111,18 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     const int64_t f0 = win_f0[w], nf = win_nf[w];
     AF_HIP(hipStreamWaitEvent(syn, ana_done[w], 0));
     if (fin && fin != syn && w >= depth) AF_HIP(hipStreamWaitEvent(syn, syn_done[w - depth], 0));  // its pitch-spectrum buffer is free
-    AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w], fin));
+    {
+      hipStream_t net = nullptr;
+      hipEvent_t spec_done = nullptr;
+      if (rnn_own_stream && fin && fin != syn && e->rnn_stream) {
+        net = e->rnn_stream;
+        if (int rc = next_event(&spec_done)) return rc;
+      } else if (rnn_on_caller && persistent && fin && fin != syn && syn != stream) {
+        net = stream;  // the caller's stream: a queue the process has anyway, idle between the call's fork and its join
+        if (int rc = next_event(&spec_done)) return rc;
+      }
+      AF_HIP(af::launch_suppressor_synthesis(window_args(f0, nf, w), e->supp.tables, e->supp.dw, syn, rnn_done[w], fin, net, spec_done));
+    }
     if (e->trace) {  // the window's (silence, pitch index) decisions, before its record buffer is handed back to the analysis
       const af::SuppArgs sa = window_args(f0, nf, w);
       AF_HIP(hipMemcpy2DAsync(e->d_trace + 2 * f0 * e->n_streams, 2 * sizeof(int32_t),
@@ -2158,7 +2193,12 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         for (int j = 0; j < hp.n_eq_sections; ++j) xf_w = xf_w || hp.eq[j].xf_remaining > 0;
       }
       if (ok) {
-        const hipStream_t es = e->eq_stream;  // behind the window's overlap-add, beside the next window's synthesis
+        // behind the window's overlap-add, beside the next window's synthesis (AF_EQ_ON_FIN=1: on the synthesis' own stream)
+        static const bool eq_on_fin = [] {
+          const char *env = std::getenv("AF_EQ_ON_FIN");
+          return env && std::atoi(env) != 0;
+        }();
+        const hipStream_t es = (eq_on_fin && fin && fin != syn) ? fin : e->eq_stream;
         AF_HIP(hipStreamWaitEvent(es, syn_done[w], 0));
         if (!e->d_params_eq || e->eq_params_presets != n_presets) {
           if (e->d_params_eq) AF_HIP(hipFree(e->d_params_eq));

@@ -2213,11 +2213,20 @@ hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, h
 // `after_network` (optional) is recorded right behind the network launch (see launch_suppressor_analysis).
 // `finish_stream` (optional, needs `after_network`): resynthesis and overlap-add run there, so that the next window's
 // pitch spectra and network launch can start while they run.
+// `network_stream` + `after_spectra` (both or neither): the network kernel runs there, behind the pitch-spectrum kernel's event --
+// the two are the longest pair of dependent kernels of a window, and one stream ran them back to back window after window.
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
-                                       hipEvent_t after_network, hipStream_t finish_stream) {
+                                       hipEvent_t after_network, hipStream_t finish_stream, hipStream_t network_stream,
+                                       hipEvent_t after_spectra) {
   const int64_t units = (int64_t)a.n_streams * ((a.n_frames + kFramesPerWave - 1) / kFramesPerWave);
   const unsigned cells = (unsigned)((units + kFftWaves - 1) / kFftWaves);  // four units (waves) per transform workgroup
   hipLaunchKernelGGL(supp_pitchspec_kernel, dim3(cells), dim3(64 * kFftWaves), 0, stream, a, tb);
+  if (network_stream && after_spectra && network_stream != stream) {
+    hipError_t err = hipEventRecord(after_spectra, stream);
+    if (err == hipSuccess) err = hipStreamWaitEvent(network_stream, after_spectra, 0);
+    if (err != hipSuccess) return err;
+    stream = network_stream;  // (what follows -- the network, its event -- is this stream's)
+  }
   {
     // AF_RNN_VARIANT = waves (16 streams each) per workgroup: 1, 2 or 4.  Measured on one box, full bench step:
     // 4 -> 287-290 ms, 1 -> 298 ms (the round's first network kernel, a 4-wave workgroup per 16 streams: 301 ms)

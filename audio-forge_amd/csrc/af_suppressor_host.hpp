@@ -13,7 +13,8 @@ namespace af {
 
 hipError_t launch_suppressor_analysis(const SuppArgs &a, const SuppTables &tb, hipStream_t stream, hipEvent_t before_pitch);
 hipError_t launch_suppressor_synthesis(const SuppArgs &a, const SuppTables &tb, const RnnDeviceWeights &w, hipStream_t stream,
-                                       hipEvent_t after_network, hipStream_t finish_stream);
+                                       hipEvent_t after_network, hipStream_t finish_stream, hipStream_t network_stream = nullptr,
+                                       hipEvent_t after_spectra = nullptr);
 hipError_t launch_suppressor_prefilter(const SuppArgs &a, hipStream_t stream);
 hipError_t launch_scale_probe(const float *in, float *out, int64_t n, hipStream_t stream);
 

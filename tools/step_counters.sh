@@ -30,7 +30,7 @@ for counters in "FETCH_SIZE" "WRITE_SIZE" \
   pass=$((pass + 1))
   rm -rf "gpurun_out/stepc_${pass}"
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc $counters --kernel-trace --output-format csv -d "$root/gpurun_out/stepc_${pass}" -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$root/gpurun_out/stepc_${pass}.log" 2>&1 || true )
-  python tools/pmc_summary.py "gpurun_out/stepc_${pass}" "gpurun_out/stepc_${pass}.json" supp_ chain_ eq_systolic stage_ > /dev/null || echo "pass ${pass} (${counters}) produced no counters"
+  python tools/pmc_summary.py "gpurun_out/stepc_${pass}" "gpurun_out/stepc_${pass}.json" supp_ chain_ eq_systolic eq_stream stage_ > /dev/null || echo "pass ${pass} (${counters}) produced no counters"
   rm -rf "gpurun_out/stepc_${pass}"
 done
 python tools/step_counters.py "$@"
