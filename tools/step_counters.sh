@@ -14,7 +14,7 @@ python - <<'PY'
 import csv, glob
 rows = []
 for path in glob.glob("gpurun_out/stepc_0/**/*kernel_stats.csv", recursive=True):
-    rows += [r for r in csv.DictReader(open(path)) if any(t in r["Name"] for t in ("supp_", "chain_", "eq_systolic", "stage_", "deesser", "resample"))]
+    rows += [r for r in csv.DictReader(open(path)) if any(t in r["Name"] for t in ("supp_", "chain_", "eq_systolic", "eq_stream", "stage_", "deesser", "resample"))]
 if rows:
     with open("gpurun_out/stepc_kernel_stats.csv", "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
