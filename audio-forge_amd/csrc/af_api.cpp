@@ -26,6 +26,9 @@ hipError_t launch_chain_ring(const LaunchArgs &args, int n_sections, int lookahe
                              bool auto_makeup, hipStream_t stream);
 hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant, bool auto_makeup, hipStream_t stream);
 hipError_t launch_chain_publish_ready(int64_t *ready, int64_t samples, hipStream_t stream);
+hipError_t launch_eq_stream_part(const ChainParams *d_params, double *st64, const float *in, float *audio, BlockStats *stats,
+                                 double *block_power, int sec0, int count, bool head, int64_t n_samples, int64_t stream_stride,
+                                 int32_t n_streams, hipStream_t stream);
 hipError_t launch_chain_quad(const LaunchArgs &args, int n_sections, int lookahead_samples, bool crossfade, int waves,
                              hipStream_t stream);
 size_t quad_kernel_dynamic_lds(int n_sections, int lookahead_samples, bool crossfade);
@@ -164,6 +167,7 @@ struct af_engine {
   double vad_reliability = 0.0, noise_floor_db = 0.0, live_noise_reliability = 0.0;
   bool has_evidence = false;
   int32_t *d_status = nullptr;
+  bool eq_params_on_es = false;              // the EQ parameter block's last upload ran on the EQ stream (two-part EQ: who must wait for it)
   int64_t *d_ready = nullptr;                // samples of the running call the suppressor's side has finished (LaunchArgs::ready)
   int64_t stats_capacity = 0;  // rows
   float *d_io = nullptr;       // staging for the host entry point
@@ -2093,7 +2097,11 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
     AF_HIP(hipEventRecord(ana_done[w], e->ana_stream));
     return AF_OK;
   };
-  if (persistent) {  // the call's one chain launch: resident on the chain's CUs from here on, following `d_ready`
+  static const bool diag_no_chain_kernel = [] {  // AF_DIAG_NO_CHAIN_KERNEL=1 (timing experiments): everything but the chain launch
+    const char *env = std::getenv("AF_DIAG_NO_CHAIN_KERNEL");
+    return env && std::atoi(env) != 0;
+  }();
+  if (persistent && !diag_no_chain_kernel) {  // the call's one chain launch: resident on the chain's CUs from here on, following `d_ready`
     af::ChainParams run_p = run;
     run_p.flags = (run_p.flags & ~af::kFlagEq) | af::kFlagInputDone;  // (what every window's launch was given)
     const int64_t total = frames * af::kRnnFrame;
@@ -2207,10 +2215,29 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
           e->eq_params_presets = n_presets;
           e->uploaded_eq.clear();
         }
+        // AF_EQ_PARTS=2 (MEASURED, OFF): the window's EQ as TWO launches of the lane-per-stream kernel, sections [0, h) on the
+        // caller's stream and [h, n) on the EQ stream, so that the second half of window w runs beside the first half of w + 1.
+        // (With the chain launch left out of the step the EQ stream is the last to finish -- 52 x 3.2 ms = 166 ms -- hence the
+        // attempt.)  Bit-identical; on a caller-owned stream 178.0 against 176.9-178.3 ms per step: nothing, and the caller's own
+        // stream costs more than the default one (one more hardware queue).  On the legacy default stream it cannot run at all.
+        static const bool eq_two_parts_env = [] {
+          const char *env = std::getenv("AF_EQ_PARTS");
+          return env && std::atoi(env) == 2;
+        }();
+        const bool two_parts = eq_two_parts_env && persistent && n_presets == 1 && !xf_w && (runs_eq[0].flags & af::kFlagEq) &&
+                               runs_eq[0].n_eq_sections >= 2 && runs_eq[0].n_eq_sections <= 32 && stream != es && (stream_stride % 4) == 0 &&
+                               // (not the legacy default stream -- or the per-thread one: work enqueued there waits for the other
+                               // streams' earlier work, the resident chain launch included, which waits for this window; measured: the
+                               // call runs into the launch's bound.  A caller on a stream of its own gets the two-part EQ.)
+                               reinterpret_cast<uintptr_t>(stream) > 2 &&
+                               (reinterpret_cast<uintptr_t>(out + seg0) & 15) == 0 && !std::getenv("AF_EQ_STREAM_OFF");
         if (e->uploaded_eq.size() != runs_eq.size() ||
             std::memcmp(e->uploaded_eq.data(), runs_eq.data(), sizeof(af::ChainParams) * runs_eq.size()) != 0) {
           e->uploaded_eq = runs_eq;
+          // (always on the EQ stream, never the caller's: a copy on the legacy default stream waits for every other stream --
+          // the resident chain launch included, which waits for this window: the call would run into the launch's bound)
           if (int rc2 = stage_upload(e, e->d_params_eq, runs_eq.data(), runs_eq.size(), es)) return rc2;
+          if (stream != es) e->eq_params_on_es = true;
         }
         if (eq_needs_chain_done) {  // the previous window's EQ ran inside its chain launch: that launch owns the memories until it ends
           hipEvent_t chain_done;
@@ -2222,6 +2249,32 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
         if (clear_per_window) AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
         power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
+        if (two_parts) {
+          const int nsec = runs_eq[0].n_eq_sections, h = nsec / 2;
+          if (e->eq_params_on_es) {  // (an upload the EQ stream made for an earlier window: the caller's stream reads the block now)
+            hipEvent_t up;
+            if (int rc2 = next_event(&up)) return rc2;
+            AF_HIP(hipEventRecord(up, es));
+            AF_HIP(hipStreamWaitEvent(stream, up, 0));
+            e->eq_params_on_es = false;
+          }
+          AF_HIP(hipStreamWaitEvent(stream, syn_done[w], 0));
+          AF_HIP(af::launch_eq_stream_part(e->d_params_eq, e->d_st64, out + seg0, out + seg0, rows_w, nullptr, 0, h, true, seg_n,
+                                           stream_stride, e->n_streams, stream));
+          hipEvent_t half;
+          if (int rc2 = next_event(&half)) return rc2;
+          AF_HIP(hipEventRecord(half, stream));
+          AF_HIP(hipStreamWaitEvent(es, half, 0));
+          AF_HIP(af::launch_eq_stream_part(e->d_params_eq, e->d_st64, out + seg0, out + seg0, power_w ? rows_w : nullptr, power_w, h, nsec - h,
+                                           false, seg_n, stream_stride, e->n_streams, es));
+          e->last_launches += 2;
+          AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, es));
+          advance_crossfades(e, seg_n);
+          run = e->host_params;
+          if (front_flags) run.flags &= ~(front | af::kFlagInputScrub);
+          blocks_done += (seg_n + cb - 1) / cb;
+          continue;
+        }
         AF_HIP(af::launch_eq_systolic(e->d_params_eq, e->extra_presets.empty() ? nullptr : e->d_group_preset, e->d_st64, out + seg0, out + seg0, nullptr, nullptr, 0, 0,
                                       rows_w, xf_w, seg_n, stream_stride, e->n_streams, es, power_w,
                                       // the lane-per-stream form where the suppressor's kernels want the issue slots and nothing waits

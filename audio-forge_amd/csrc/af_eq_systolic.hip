@@ -43,8 +43,12 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
 // wanting a SIMD's whole issue rate (priority 2).  Same expressions in the same order as the systolic body and the chain
 // kernel's EQ units: the same bits.  Serves windows without a pending crossfade, one preset, stream-major audio with 16-byte
 // rows; everything else takes the systolic kernel.
+// `sec0`: the first of this launch's kSec sections; `head`: the launch takes the raw input (scrub / clamp apply; kStats only there).
+// A window's EQ may run as TWO launches, sections [0, h) and [h, n), on two streams: the sample between two sections is an f32
+// in the reference, so the hand-over through the audio buffer is exact, and the second half of window w runs beside the first
+// half of window w + 1 -- the EQ's period per window halves (one launch per window was the pipeline's longest stage).
 template <int kSec, bool kStats, bool kPower>
-__global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a) {
+__global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a, int sec0, int head) {
   const int lane = threadIdx.x & 63;
   const int s = blockIdx.x * 64 + lane;
   const bool valid = s < a.n_streams;
@@ -52,17 +56,17 @@ __global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a) {
   const int64_t NS = a.n_streams;
   const ChainParams &P = a.params[0];
   const uint32_t flags = P.flags;
-  const bool scrub = (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = (flags & kFlagInputClamp) != 0;
+  const bool scrub = head && (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = head && (flags & kFlagInputClamp) != 0;
   const int cb = P.control_block;
   __builtin_amdgcn_s_setprio(2);
   BiquadCoef c[kSec];
   double z1[kSec], z2[kSec];
 #pragma unroll
   for (int k = 0; k < kSec; ++k) {
-    const SectionParams &sp = P.eq[k];
+    const SectionParams &sp = P.eq[sec0 + k];
     c[k] = sp.xf_remaining > 0 ? sp.pending : sp.active;  // (a crossfade that ended in an earlier launch: see the systolic body)
-    z1[k] = a.st64[(int64_t)(kEqBase + 4 * k) * NS + sc];
-    z2[k] = a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + sc];
+    z1[k] = a.st64[(int64_t)(kEqBase + 4 * (sec0 + k)) * NS + sc];
+    z2[k] = a.st64[(int64_t)(kEqBase + 4 * (sec0 + k) + 1) * NS + sc];
   }
   const float *row_in = a.in + (int64_t)sc * a.stream_stride;
   float *row_out = a.audio + (int64_t)sc * a.stream_stride;
@@ -143,28 +147,48 @@ __global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a) {
   if (valid) {
 #pragma unroll
     for (int k = 0; k < kSec; ++k) {
-      a.st64[(int64_t)(kEqBase + 4 * k) * NS + s] = z1[k];
-      a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + s] = z2[k];
+      a.st64[(int64_t)(kEqBase + 4 * (sec0 + k)) * NS + s] = z1[k];
+      a.st64[(int64_t)(kEqBase + 4 * (sec0 + k) + 1) * NS + s] = z2[k];
     }
   }
 }
 
 template <int kSec>
-static void launch_eq_stream_sections(const EqSystolicArgs &a, bool stats, bool power, hipStream_t stream) {
+static void launch_eq_stream_sections(const EqSystolicArgs &a, bool stats, bool power, int sec0, bool head, hipStream_t stream) {
   const dim3 grid((unsigned)((a.n_streams + 63) / 64)), block(64);
-  if (power) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, true>), grid, block, 0, stream, a);
-  else if (stats) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, false>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((eq_stream_kernel<kSec, false, false>), grid, block, 0, stream, a);
+  const int h = head ? 1 : 0;
+  if (power && stats) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, true>), grid, block, 0, stream, a, sec0, h);
+  else if (power) hipLaunchKernelGGL((eq_stream_kernel<kSec, false, true>), grid, block, 0, stream, a, sec0, h);
+  else if (stats) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, false>), grid, block, 0, stream, a, sec0, h);
+  else hipLaunchKernelGGL((eq_stream_kernel<kSec, false, false>), grid, block, 0, stream, a, sec0, h);
 }
-static bool launch_eq_stream(const EqSystolicArgs &a, int n_sections, bool stats, bool power, hipStream_t stream) {
+static bool launch_eq_stream(const EqSystolicArgs &a, int n_sections, bool stats, bool power, hipStream_t stream, int sec0 = 0,
+                             bool head = true) {
   switch (n_sections) {
-#define AF_EQ_STREAM_CASE(k) case k: launch_eq_stream_sections<k>(a, stats, power, stream); return true;
+#define AF_EQ_STREAM_CASE(k) case k: launch_eq_stream_sections<k>(a, stats, power, sec0, head, stream); return true;
     AF_EQ_STREAM_CASE(1) AF_EQ_STREAM_CASE(2) AF_EQ_STREAM_CASE(3) AF_EQ_STREAM_CASE(4) AF_EQ_STREAM_CASE(5) AF_EQ_STREAM_CASE(6)
     AF_EQ_STREAM_CASE(7) AF_EQ_STREAM_CASE(8) AF_EQ_STREAM_CASE(9) AF_EQ_STREAM_CASE(10) AF_EQ_STREAM_CASE(11) AF_EQ_STREAM_CASE(12)
     AF_EQ_STREAM_CASE(13) AF_EQ_STREAM_CASE(14) AF_EQ_STREAM_CASE(15) AF_EQ_STREAM_CASE(16)
 #undef AF_EQ_STREAM_CASE
     default: return false;
   }
+}
+
+// One half of a window's EQ in the lane-per-stream form: sections [sec0, sec0 + count) of the single preset.  `head`: this launch
+// takes the raw input (scrub / clamp, block input statistics into `stats`); a launch that ends at the last section may keep the
+// block powers (`block_power`).  Returns hipErrorNotSupported when the form does not serve the buffers (the caller then runs the
+// whole EQ through launch_eq_systolic).
+hipError_t launch_eq_stream_part(const ChainParams *d_params, double *st64, const float *in, float *audio, BlockStats *stats,
+                                 double *block_power, int sec0, int count, bool head, int64_t n_samples, int64_t stream_stride,
+                                 int32_t n_streams, hipStream_t stream) {
+  if (count <= 0 || count > 16 || (stream_stride % 4) != 0 || !audio ||
+      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(audio)) & 15) != 0)
+    return hipErrorNotSupported;
+  EqSystolicArgs a{d_params, nullptr, st64, in, audio, nullptr, nullptr, head ? stats : nullptr, n_samples, stream_stride, 0, n_streams, 0,
+                   block_power};
+  // (block powers are kept together with block rows: the kernel's flush writes both; without `stats` the rows are skipped)
+  if (!launch_eq_stream(a, count, head && stats != nullptr, block_power != nullptr, stream, sec0, head)) return hipErrorNotSupported;
+  return hipGetLastError();
 }
 
 // `audio`: stream-major output (may be `in`); or null and `ring` / `ring_in` / `ring_rows` / `n0`: the stage pipeline's rings.

@@ -400,6 +400,8 @@ def main() -> None:
         engine.set_prefilter_enabled(1, 1)   # DC block + 80 Hz high-pass, routing.rs:826-843
         engine.set_suppressor_enabled(1)     # RNNoise, rnnoise.rs:122-164 (synthetic weights: trained ones are not offline)
     engine.set_timing_enabled(1)
+    # (torch's current stream, i.e. the default one: a stream of the caller's own is one more hardware queue for the process, and the
+    # engine's eight are at the point where one more makes two pipeline stages share a queue -- 172 -> 177 ms per step)
     hip_stream = torch.cuda.current_stream().cuda_stream
 
     def step() -> None:
