@@ -23,9 +23,16 @@ from mic_eq_mi import mic_eq_core as core
 audio = S.batch_signal(70, 230)  # 70 streams (64 + 6), 2.3 s: ramped windows, two calls
 bands = [(80.0 * 1.75**i, 3.0 if i % 2 else -2.5, 1.0) for i in range(10)]  # legacy setters: a crossfade opens the stream
 eng = core.Engine(48_000.0, 70)
-core.configure_auto_eq_chain(eng, 48_000.0, bands, S.limiter_settings(2.0))
-eng.set_prefilter_enabled(1, 1)
-eng.set_suppressor_enabled(1)
+# AB_MODE: "full" (default: front end + suppressor + chain), "dynamics" (no suppressor), "+automakeup" appended: the compressor's
+# auto-makeup on -- the execution forms differ per mode (one chain launch following the suppressor / following the systolic EQ)
+mode = os.environ.get("AB_MODE", "full")
+settings = dict(S.limiter_settings(2.0))
+if mode.endswith("+automakeup"):
+    settings.update(compressor_auto_makeup_enabled=True, compressor_target_lufs=-18.0)
+core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)
+if mode.startswith("full"):
+    eng.set_prefilter_enabled(1, 1)
+    eng.set_suppressor_enabled(1)
 ys, rows = [], []
 for lo, hi in ((0, 130 * 480), (130 * 480, 230 * 480)):
     ys.append(eng.process(audio[:, lo:hi]))
