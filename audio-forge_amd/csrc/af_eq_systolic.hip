@@ -58,7 +58,9 @@ __global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a, int sec
   const uint32_t flags = P.flags;
   const bool scrub = head && (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = head && (flags & kFlagInputClamp) != 0;
   const int cb = P.control_block;
+#ifndef AF_EQ_STREAM_NO_PRIO
   __builtin_amdgcn_s_setprio(2);
+#endif
   BiquadCoef c[kSec];
   double z1[kSec], z2[kSec];
 #pragma unroll
