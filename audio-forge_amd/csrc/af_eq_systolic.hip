@@ -47,10 +47,16 @@ __global__ __launch_bounds__(64) void eq_systolic_kernel(EqSystolicArgs a) {
 // A window's EQ may run as TWO launches, sections [0, h) and [h, n), on two streams: the sample between two sections is an f32
 // in the reference, so the hand-over through the audio buffer is exact, and the second half of window w runs beside the first
 // half of window w + 1 -- the EQ's period per window halves (one launch per window was the pipeline's longest stage).
+// Four waves (four 64-stream groups) per workgroup, one per SIMD of a CU: a wave of this kernel holds ~240 vector registers -- half
+// a SIMD's file -- for milliseconds; one such wave per CU on 64 CUs takes two of three wave slots away from the 169-register
+// transform kernels on a third of the suppressor's CUs (their workgroups need a slot on every SIMD).  Packed, sixteen CUs carry them.
+constexpr int kEqStreamWaves = 4;
 template <int kSec, bool kStats, bool kPower>
-__global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a, int sec0, int head) {
+__global__ __launch_bounds__(64 * kEqStreamWaves) void eq_stream_kernel(EqSystolicArgs a, int sec0, int head) {
   const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 64 + lane;
+  const int group = blockIdx.x * kEqStreamWaves + (threadIdx.x >> 6);
+  if (group * 64 >= a.n_streams) return;  // (no workgroup barrier in this kernel)
+  const int s = group * 64 + lane;
   const bool valid = s < a.n_streams;
   const int sc = valid ? s : a.n_streams - 1;
   const int64_t NS = a.n_streams;
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(64) void eq_stream_kernel(EqSystolicArgs a, int sec
 
 template <int kSec>
 static void launch_eq_stream_sections(const EqSystolicArgs &a, bool stats, bool power, int sec0, bool head, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.n_streams + 63) / 64)), block(64);
+  const unsigned groups = (unsigned)((a.n_streams + 63) / 64);
+  const dim3 grid((groups + kEqStreamWaves - 1) / kEqStreamWaves), block(64 * kEqStreamWaves);
   const int h = head ? 1 : 0;
   if (power && stats) hipLaunchKernelGGL((eq_stream_kernel<kSec, true, true>), grid, block, 0, stream, a, sec0, h);
   else if (power) hipLaunchKernelGGL((eq_stream_kernel<kSec, false, true>), grid, block, 0, stream, a, sec0, h);
