@@ -161,6 +161,210 @@ __global__ __launch_bounds__(64 * kEqStreamWaves) void eq_stream_kernel(EqSystol
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The lane-per-stream EQ with its sections split over TWO waves per 64-stream group: the head wave runs sections [0, kSecA), drops
+// its output -- an f32 in the reference as well -- into an LDS ring, the tail wave takes it through [kSecA, kSecA + kSecB) and
+// stores the audio.  Same arithmetic, half the dependent work per wave: a window's EQ takes half as long (as one wave per group it
+// had become the pipeline's longest stage: 52 windows x 3.3 ms = the step).  Four groups = eight waves per workgroup, two per
+// SIMD.  Ring: kRingBlocks blocks of 16 samples per group; `produced` / `consumed` count blocks (workgroup-scope release / acquire,
+// one writer each).  Bounded polls: a partner that never arrives ends the wait after ~1 s and the kernel runs out (garbage audio,
+// never expected: both waves of a group are of the same workgroup and resident together).  Serves sample counts that are multiples
+// of four; anything else takes the one-wave kernel.
+constexpr int kEq2Groups = 2, kEq2RingBlocks = 4, kEq2BlockQuads = 4;  // (two groups = four waves: one per SIMD -- with four groups two waves share a SIMD and each runs at half speed: nothing gained)
+struct Eq2Lds {
+  float4 ring[kEq2Groups][kEq2RingBlocks][kEq2BlockQuads][64];
+  int produced[kEq2Groups], consumed[kEq2Groups];
+};
+template <int kSecA, int kSecB, bool kStats, bool kPower>
+__global__ __launch_bounds__(128 * kEq2Groups) void eq_stream2_kernel(EqSystolicArgs a) {
+  __shared__ Eq2Lds L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = wave >> 1;
+  const bool head = (wave & 1) == 0;
+  if (threadIdx.x < kEq2Groups) { L.produced[threadIdx.x] = 0; L.consumed[threadIdx.x] = 0; }
+  __syncthreads();
+  const int group = blockIdx.x * kEq2Groups + g;
+  if (group * 64 >= a.n_streams) return;  // (both waves of the group leave: no barrier after this point)
+  const int s = group * 64 + lane;
+  const bool valid = s < a.n_streams;
+  const int sc = valid ? s : a.n_streams - 1;
+  const int64_t NS = a.n_streams;
+  const ChainParams &P = a.params[0];
+  const uint32_t flags = P.flags;
+  const int cb = P.control_block;
+  const int64_t quads = a.n_samples >> 2;
+  const int64_t blocks = (quads + kEq2BlockQuads - 1) / kEq2BlockQuads;
+  __builtin_amdgcn_s_setprio(2);
+  auto wait_for = [&](int *word, int64_t at_least) {
+    int spins = 0;
+    while ((int64_t)__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < at_least) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) break;
+    }
+  };
+  if (head) {
+    constexpr int kSec = kSecA;
+    const bool scrub = (flags & (kFlagInputScrub | kFlagInputClamp)) != 0, clamp = (flags & kFlagInputClamp) != 0;
+    BiquadCoef c[kSec];
+    double z1[kSec], z2[kSec];
+#pragma unroll
+    for (int k = 0; k < kSec; ++k) {
+      const SectionParams &sp = P.eq[k];
+      c[k] = sp.xf_remaining > 0 ? sp.pending : sp.active;
+      z1[k] = a.st64[(int64_t)(kEqBase + 4 * k) * NS + sc];
+      z2[k] = a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + sc];
+    }
+    const float *row_in = a.in + (int64_t)sc * a.stream_stride;
+    double in_sq = 0.0;
+    float in_peak = 0.0f;
+    int64_t block_index = 0;
+    int in_block = 0;
+    auto sample = [&](float v) -> float {
+      if (scrub && !finite_f32(v)) v = 0.0f;
+      if (clamp) v = fclamp(v, -1.0f, 1.0f);
+      if (kStats) {
+        const double xd0 = (double)v;
+        in_sq += xd0 * xd0;
+        in_peak = fmaxf(in_peak, fabsf(v));
+      }
+      float x = v;
+#pragma unroll
+      for (int k = 0; k < kSec; ++k) {
+        const double xd = (double)x;
+        const double y = c[k].b0 * xd + z1[k];
+        z1[k] = c[k].b1 * xd - c[k].a1 * y + z2[k];
+        z2[k] = c[k].b2 * xd - c[k].a2 * y;
+        x = (float)y;
+      }
+      return x;
+    };
+    auto flush = [&]() {
+      if (kStats && valid && a.stats) {
+        BlockStats &r = a.stats[block_index * NS + s];
+        r.input_square_sum = in_sq;
+        r.input_sample_peak = in_peak;
+      }
+      block_index += 1;
+      in_block = 0;
+      in_sq = 0.0;
+      in_peak = 0.0f;
+    };
+    float4 v0 = quads > 0 ? *reinterpret_cast<const float4 *>(row_in) : make_float4(0, 0, 0, 0);
+    float4 v1 = quads > 1 ? *reinterpret_cast<const float4 *>(row_in + 4) : make_float4(0, 0, 0, 0);
+    for (int64_t b = 0; b < blocks; ++b) {
+      if (b >= kEq2RingBlocks) wait_for(&L.consumed[g], b - kEq2RingBlocks + 1);  // the slot has been read
+      float4(&slot)[kEq2BlockQuads][64] = L.ring[g][b % kEq2RingBlocks];
+#pragma unroll
+      for (int j = 0; j < kEq2BlockQuads; ++j) {
+        const int64_t q = b * kEq2BlockQuads + j;
+        if (q < quads) {
+          const float4 v2 = q + 2 < quads ? *reinterpret_cast<const float4 *>(row_in + 4 * (q + 2)) : make_float4(0, 0, 0, 0);
+          float t[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            t[u] = sample(t[u]);
+            if (++in_block == cb) flush();
+          }
+          slot[j][lane] = make_float4(t[0], t[1], t[2], t[3]);
+          v0 = v1;
+          v1 = v2;
+        }
+      }
+      __hip_atomic_store(&L.produced[g], (int)(b + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (in_block > 0) flush();
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < kSec; ++k) {
+        a.st64[(int64_t)(kEqBase + 4 * k) * NS + s] = z1[k];
+        a.st64[(int64_t)(kEqBase + 4 * k + 1) * NS + s] = z2[k];
+      }
+    }
+  } else {
+    constexpr int kSec = kSecB;
+    BiquadCoef c[kSec];
+    double z1[kSec], z2[kSec];
+#pragma unroll
+    for (int k = 0; k < kSec; ++k) {
+      const SectionParams &sp = P.eq[kSecA + k];
+      c[k] = sp.xf_remaining > 0 ? sp.pending : sp.active;
+      z1[k] = a.st64[(int64_t)(kEqBase + 4 * (kSecA + k)) * NS + sc];
+      z2[k] = a.st64[(int64_t)(kEqBase + 4 * (kSecA + k) + 1) * NS + sc];
+    }
+    float *row_out = a.audio + (int64_t)sc * a.stream_stride;
+    double out_sq = 0.0;
+    int64_t block_index = 0;
+    int in_block = 0;
+    auto sample = [&](float x) -> float {
+#pragma unroll
+      for (int k = 0; k < kSec; ++k) {
+        const double xd = (double)x;
+        const double y = c[k].b0 * xd + z1[k];
+        z1[k] = c[k].b1 * xd - c[k].a1 * y + z2[k];
+        z2[k] = c[k].b2 * xd - c[k].a2 * y;
+        x = (float)y;
+      }
+      if (kPower) {
+        const double yd = (double)x;
+        out_sq += finite_f32(x) ? yd * yd : 0.0;
+      }
+      return x;
+    };
+    auto flush = [&]() {
+      if (kPower && valid) a.block_power[block_index * NS + s] = out_sq;
+      block_index += 1;
+      in_block = 0;
+      out_sq = 0.0;
+    };
+    for (int64_t b = 0; b < blocks; ++b) {
+      wait_for(&L.produced[g], b + 1);
+      float4(&slot)[kEq2BlockQuads][64] = L.ring[g][b % kEq2RingBlocks];
+#pragma unroll
+      for (int j = 0; j < kEq2BlockQuads; ++j) {
+        const int64_t q = b * kEq2BlockQuads + j;
+        if (q < quads) {
+          const float4 v = slot[j][lane];
+          float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            t[u] = sample(t[u]);
+            if (++in_block == cb) flush();
+          }
+          if (valid) *reinterpret_cast<float4 *>(row_out + 4 * q) = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      __hip_atomic_store(&L.consumed[g], (int)(b + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (in_block > 0) flush();
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < kSec; ++k) {
+        a.st64[(int64_t)(kEqBase + 4 * (kSecA + k)) * NS + s] = z1[k];
+        a.st64[(int64_t)(kEqBase + 4 * (kSecA + k) + 1) * NS + s] = z2[k];
+      }
+    }
+  }
+}
+template <int kSecA, int kSecB>
+static void launch_eq_stream2_sections(const EqSystolicArgs &a, bool stats, bool power, hipStream_t stream) {
+  const unsigned groups = (unsigned)((a.n_streams + 63) / 64);
+  const dim3 grid((groups + kEq2Groups - 1) / kEq2Groups), block(128 * kEq2Groups);
+  if (power) hipLaunchKernelGGL((eq_stream2_kernel<kSecA, kSecB, true, true>), grid, block, 0, stream, a);
+  else if (stats) hipLaunchKernelGGL((eq_stream2_kernel<kSecA, kSecB, true, false>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((eq_stream2_kernel<kSecA, kSecB, false, false>), grid, block, 0, stream, a);
+}
+static bool launch_eq_stream2(const EqSystolicArgs &a, int n_sections, bool stats, bool power, hipStream_t stream) {
+  if ((a.n_samples & 3) != 0) return false;
+  switch (n_sections) {
+#define AF_EQ_STREAM2_CASE(n) case n: launch_eq_stream2_sections<(n) / 2, (n) - (n) / 2>(a, stats, power, stream); return true;
+    AF_EQ_STREAM2_CASE(2) AF_EQ_STREAM2_CASE(3) AF_EQ_STREAM2_CASE(4) AF_EQ_STREAM2_CASE(5) AF_EQ_STREAM2_CASE(6) AF_EQ_STREAM2_CASE(7)
+    AF_EQ_STREAM2_CASE(8) AF_EQ_STREAM2_CASE(9) AF_EQ_STREAM2_CASE(10) AF_EQ_STREAM2_CASE(11) AF_EQ_STREAM2_CASE(12) AF_EQ_STREAM2_CASE(13)
+    AF_EQ_STREAM2_CASE(14) AF_EQ_STREAM2_CASE(15) AF_EQ_STREAM2_CASE(16)
+#undef AF_EQ_STREAM2_CASE
+    default: return false;
+  }
+}
+
 template <int kSec>
 static void launch_eq_stream_sections(const EqSystolicArgs &a, bool stats, bool power, int sec0, bool head, hipStream_t stream) {
   const unsigned groups = (unsigned)((a.n_streams + 63) / 64);
@@ -218,6 +422,11 @@ hipError_t launch_eq_systolic(const ChainParams *d_params, const int32_t *d_grou
   }();
   if (stream_form && n_sections > 0 && !crossfade && !d_group_preset && audio && !ring && (stream_stride % 4) == 0 &&
       ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(audio)) & 15) == 0 && (!block_power || stats)) {
+    static const bool two_waves = [] {  // AF_EQ_STREAM=1: one wave per group (all sections); default: two waves, sections split
+      const char *env = std::getenv("AF_EQ_STREAM");
+      return !env || std::atoi(env) != 1;
+    }();
+    if (two_waves && launch_eq_stream2(a, n_sections, stats != nullptr, block_power != nullptr, stream)) return hipGetLastError();
     if (launch_eq_stream(a, n_sections, stats != nullptr, block_power != nullptr, stream)) return hipGetLastError();
   }
   const dim3 grid((unsigned)((n_streams + 3) / 4)), block(64);
