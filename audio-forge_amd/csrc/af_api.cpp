@@ -2246,6 +2246,10 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
           AF_HIP(hipStreamWaitEvent(es, chain_done, 0));
           eq_needs_chain_done = false;
         }
+        static const bool eq_stream_with_power = [] {  // AF_EQ_STREAM_POWER=0: auto-makeup windows keep the systolic kernel
+          const char *env = std::getenv("AF_EQ_STREAM_POWER");
+          return !env || std::atoi(env) != 0;
+        }();
         af::BlockStats *rows_w = e->d_stats + blocks_done * e->n_streams;
         if (clear_per_window) AF_HIP(hipMemsetAsync(rows_w, 0, sizeof(af::BlockStats) * ((seg_n + cb - 1) / cb) * e->n_streams, es));
         power_w = auto_makeup_call ? e->d_block_power + blocks_done * e->n_streams : nullptr;
@@ -2279,7 +2283,7 @@ int af_engine_process_device(af_engine *e, const float *in, float *out, int64_t 
                                       rows_w, xf_w, seg_n, stream_stride, e->n_streams, es, power_w,
                                       // the lane-per-stream form where the suppressor's kernels want the issue slots and nothing waits
                                       // for the EQ's own latency (an auto-makeup window's block powers do): 184.5 -> 182.4 ms per step
-                                      (n_presets == 1 && !power_w && (runs_eq[0].flags & af::kFlagEq)) ? runs_eq[0].n_eq_sections : -1));
+                                      (n_presets == 1 && (!power_w || eq_stream_with_power) && (runs_eq[0].flags & af::kFlagEq)) ? runs_eq[0].n_eq_sections : -1));
         e->last_launches += 1;
         if (persistent) {  // the running chain launch picks the window up from here
           AF_HIP(af::launch_chain_publish_ready(e->d_ready, seg0 + seg_n, es));
