@@ -30,9 +30,16 @@ def _same(a: str, b: str) -> None:
 @pytest.mark.parametrize("mode", ["full", "full+automakeup", "dynamics", "dynamics+automakeup"])
 def test_one_launch_forms_equal_the_per_window_forms(mode):
     tag = mode.replace("+", "_")
-    _run(f"t_{tag}_default", mode)
-    _run(f"t_{tag}_per_window", mode, AF_CHAIN_PERSISTENT="0", AF_EQ_STREAM="0")
-    _same(f"t_{tag}_default", f"t_{tag}_per_window")
-    if mode.startswith("full"):
-        _run(f"t_{tag}_eq_in_chain", mode, AF_EQ_OFFLOAD="0")
-        _same(f"t_{tag}_default", f"t_{tag}_eq_in_chain")
+    tags = [f"t_{tag}_default", f"t_{tag}_per_window", f"t_{tag}_eq_in_chain"]
+    try:
+        _run(tags[0], mode)
+        _run(tags[1], mode, AF_CHAIN_PERSISTENT="0", AF_EQ_STREAM="0")
+        _same(tags[0], tags[1])
+        if mode.startswith("full"):
+            _run(tags[2], mode, AF_EQ_OFFLOAD="0")
+            _same(tags[0], tags[2])
+    finally:  # (26 MB each: gpurun only brings 64 MiB of gpurun_out/ back)
+        for t in tags:
+            path = os.path.join(ROOT, "gpurun_out", f"abfc_{t}.npz")
+            if os.path.exists(path):
+                os.remove(path)
