@@ -121,10 +121,28 @@ __device__ __forceinline__ void token_pass(int *turn_base, int tok, int q) {
   // chunk, and every unit is first-come-first-served, so the oldest chunk gates all others): chain time 237 -> 216 ms
   // per bench step on top of the in-unit priority (four levels; with three 219 ms; making the in-unit priority follow the
   // stage as well: 245 ms).
+#ifndef AF_PRIO_SCHEME
+#define AF_PRIO_SCHEME 0
+#endif
+#if AF_PRIO_SCHEME == 0
   if (tok == kTokEq0 + 1 || tok == kTokCompA) __builtin_amdgcn_s_setprio(1);
   else if (tok == kTokCompC || tok == kTokCompE) __builtin_amdgcn_s_setprio(2);
   else if (tok == kTokLim || tok == kTokTp) __builtin_amdgcn_s_setprio(3);
   else __builtin_amdgcn_s_setprio(0);
+#elif AF_PRIO_SCHEME == 1  // (A/B builds) one level up from the compressor's first unit on
+  if (tok == kTokEq0 + 1 || tok == kTokCompA) __builtin_amdgcn_s_setprio(2);
+  else if (tok == kTokCompC || tok == kTokCompE) __builtin_amdgcn_s_setprio(3);
+  else if (tok == kTokLim || tok == kTokTp) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+#elif AF_PRIO_SCHEME == 2  // flat: 1 everywhere between units
+  if (tok == kTokFin) __builtin_amdgcn_s_setprio(0);
+  else __builtin_amdgcn_s_setprio(1);
+#elif AF_PRIO_SCHEME == 3  // steeper at the front: the chunk's first feed-forward zone (loads) at 1 already
+  if (tok == kTokEq0 + 1 || tok == kTokCompA) __builtin_amdgcn_s_setprio(2);
+  else if (tok == kTokCompC) __builtin_amdgcn_s_setprio(2);
+  else if (tok == kTokCompE || tok == kTokLim || tok == kTokTp) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(1);
+#endif
   __builtin_amdgcn_sched_barrier(0);
 }
 
