@@ -70,9 +70,9 @@ __host__ __device__ inline size_t ring_lds_bytes(int n_sections, int lookahead, 
 // unit past the unit's token wait (earlier loads and pure arithmetic may legally move below an acquire), where it lengthens the
 // time the token is held -- the kernel's period is its longest unit.  -DAF_NO_FF_PINS builds without (A/B).
 // AF_PIN_MASK (A/B builds): 1 = in front of the peak-envelope unit, 2 = gain-reduction smoothing, 4 = limiter, 8 = true-peak
-// limiter, 16 = final fold.
+// limiter, 16 = final fold, 32 = the linear gains in front of the auto-makeup build's meter unit.
 #ifndef AF_PIN_MASK
-#define AF_PIN_MASK (2 | 16)
+#define AF_PIN_MASK (2 | 16 | 32)
 #endif
 #define AF_PIN(bit, v) do { if constexpr (((AF_PIN_MASK) & (bit)) != 0) asm volatile("" : "+v"(v)); } while (0)
 constexpr int kAbortSlot = 32;
@@ -664,7 +664,10 @@ __global__ __launch_bounds__(kRingWaves *kLanes) void chain_ring_kernel(LaunchAr
           double glin[kChunk];
   #pragma unroll
           for (int k = 0; k < kChunk; ++k)
-            if (kFull || k < len) glin[k] = db2lin(-gr_k[k]);
+            if (kFull || k < len) {
+              glin[k] = db2lin(-gr_k[k]);
+              AF_PIN(32, glin[k]);
+            }
           // ---- token: makeup gain of THIS block, loudness meter, auto-makeup controller at block end
           token_wait(turn, kTokMeter, q);
           {
@@ -1094,7 +1097,9 @@ hipError_t launch_chain_ring_lds(const LaunchArgs &args, size_t dyn, int variant
     // in flight (the kernel is a closed queueing network of its waves)
     static const int waves = [] {
       const char *env = std::getenv("AF_AUTO_WAVES");
-      return env ? std::atoi(env) : 12;  // full bench step with auto-makeup, same box: 8 -> 276 ms, 12 -> 228, 16 -> 232 (plain chain: 203)
+      // full bench step with auto-makeup, same box: round 3's first build 8 -> 276 ms, 12 -> 228, 16 -> 232 (plain chain: 203); final
+      // build (EQ off this kernel, one launch per call, the last unit freed of the detector's FIR): 8 -> 222.7, 12 -> 184.4, 16 -> 179.9
+      return env ? std::atoi(env) : 16;
     }();
     if (waves == 8) return launch_variant<8, 4, true>(args, dyn, stream);
     if (waves == 12) return launch_variant<12, 4, true>(args, dyn, stream);
