@@ -27,7 +27,7 @@ def _same(a: str, b: str) -> None:
     assert done.returncode == 0, done.stdout + done.stderr[-1000:]
 
 
-@pytest.mark.parametrize("mode", ["full", "full+automakeup", "dynamics", "dynamics+automakeup"])
+@pytest.mark.parametrize("mode", ["full", "full+automakeup", "dynamics", "dynamics+automakeup", "full+steep"])
 def test_one_launch_forms_equal_the_per_window_forms(mode):
     tag = mode.replace("+", "_")
     tags = [f"t_{tag}_default", f"t_{tag}_per_window", f"t_{tag}_eq_in_chain"]

@@ -27,8 +27,14 @@ eng = core.Engine(48_000.0, 70)
 # auto-makeup on -- the execution forms differ per mode (one chain launch following the suppressor / following the systolic EQ)
 mode = os.environ.get("AB_MODE", "full")
 settings = dict(S.limiter_settings(2.0))
-if mode.endswith("+automakeup"):
+if "+automakeup" in mode:
     settings.update(compressor_auto_makeup_enabled=True, compressor_target_lufs=-18.0)
+if "+steep" in mode:  # typed bands with steep slopes: 15 EQ sections instead of 10 (odd: the two-wave EQ kernel splits them 7 + 8)
+    steep = list(S.DEFAULT_TYPED_BANDS)
+    steep[0] = ("high_pass", 90.0, 0.0, 0.707, 48, True)    # four sections
+    steep[9] = ("low_pass", 15000.0, 0.0, 0.707, 36, True)  # three sections
+    steep[4] = ("bell", 1000.0, 6.0, 2.0, 12, True)
+    settings["eq_bands_v2"] = steep
 core.configure_auto_eq_chain(eng, 48_000.0, bands, settings)
 if mode.startswith("full"):
     eng.set_prefilter_enabled(1, 1)
