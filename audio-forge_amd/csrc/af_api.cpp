@@ -209,7 +209,10 @@ struct af_engine {
     int32_t w_min = 1;                     // smallest lookahead + 1 over the presets
     uint32_t strip = 0;                    // chain flags another kernel has taken over (the suppressor's pre-pass)
   } pipe;
-  int supp_window_frames = 20;  // measured 12..80 (AF_SUPP_WINDOW_FRAMES): 20 -> 248 ms per bench step, 24 -> 252, 30 -> 254, 16 -> 259, 50 -> 260
+  // measured 12..80 (AF_SUPP_WINDOW_FRAMES).  Round 1 (one chain launch per window): 20 -> 248 ms per bench step, 24 -> 252, 30 ->
+  // 254, 16 -> 259, 50 -> 260.  End of round 3 (one chain launch per call: a window costs the chain nothing any more):
+  // 12 -> 165.2, 14 -> 166.1, 16 -> 163.2, 18 -> 164.5, 20 -> 165.0, 24 -> 166.7, 32 -> 169.2
+  int supp_window_frames = 16;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_mid = nullptr;  // start | suppressor done | chain done
 
   af_engine(double fs, int n, int dev) : proto(fs), n_streams(n), device(dev) {}
